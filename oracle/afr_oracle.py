@@ -1,0 +1,241 @@
+"""CPU ORACLE -- TEST INFRASTRUCTURE ONLY.  Not part of the product path.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this file; the
+product (ai-font-renderer_amd/) never does and fails loudly when libafr.so is missing.
+
+What it is: a first-principles restatement, in explicit tensor algebra (no torch.nn modules, no
+autograd), of the arithmetic the reference's training step performs.  The reference's arithmetic
+lives in its third-party dependency `torch` (requirements.txt:2, unpinned `torch>=1.7.0`; this
+image has 2.10.0+rocm7.0); the call sites restated here are cited per function.  PARITY PINNING:
+the reference has no tests or golden vectors of its own, so this restatement is pinned against
+outputs of the reference itself, imported in the build container by tests/golden/make_golden.py
+(fixtures committed under tests/golden/*.npz, checked by tests/test_oracle_golden.py).
+
+Every function works in the dtype of the tensors it is given (float32 for parity runs, float64
+for tight self-checks).  Dropout masks are INPUTS (0/1 tensors); eval mode = masks None.
+"""
+import math
+import torch
+
+
+# --------------------------------------------------------------------------- sheet model (R0)
+def sheet_forward(P, x, cfg, masks=None):
+    """AttentionFontRenderer.forward, reference model.py:158-204.
+
+    P: dict of the 12 state_dict tensors (model.py:136-152).  x: int64 [B, Lin].
+    masks: None (eval) or dict(embed=[B,L,E], attn=[B,H,L,L], fc=[B,L,F]) of {0,1}.
+    Returns (y [B,h,w], cache) -- cache holds what sheet_backward needs.
+    """
+    B, Lin = x.shape
+    L = min(Lin, cfg.max_length)                                  # model.py:163-164
+    x = x[:, :L]
+    E, H, F = cfg.embed_dim, cfg.heads, cfg.fc_dim
+    D = E // H
+    dt = P["embedding.weight"].dtype
+    e0 = P["embedding.weight"][x]                                  # gather, model.py:167
+    if masks is not None:                                          # dropout BEFORE pos-enc, :168
+        se = 1.0 / (1.0 - cfg.p_embed)
+        e1 = e0 * (masks["embed"].to(dt) * se)
+    else:
+        e1 = e0
+    e = e1 + P["positional_encoding"][:L].unsqueeze(0)             # model.py:171-172
+    # nn.MultiheadAttention math path (torch/nn/functional.py multi_head_attention_forward,
+    # need_weights=True, batch_first=False): packed in-proj, q scaled by sqrt(1/D), softmax,
+    # dropout on probabilities, out-proj.  model.py:144,175-177
+    qkv = e @ P["attention.in_proj_weight"].t() + P["attention.in_proj_bias"]
+    q, k, v = qkv.split(E, dim=-1)
+
+    def heads(t):
+        return t.reshape(B, L, H, D).permute(0, 2, 1, 3)           # [B,H,L,D]
+
+    qh, kh, vh = heads(q), heads(k), heads(v)
+    scale = math.sqrt(1.0 / D)
+    S = (qh * scale) @ kh.transpose(-1, -2)                        # [B,H,L,L]
+    A = torch.softmax(S, dim=-1)
+    if masks is not None:
+        sa = 1.0 / (1.0 - cfg.p_attn)
+        Ad = A * (masks["attn"].to(dt) * sa)
+    else:
+        Ad = A
+    o = (Ad @ vh).permute(0, 2, 1, 3).reshape(B, L, E)
+    a = o @ P["attention.out_proj.weight"].t() + P["attention.out_proj.bias"]
+    r = e + a                                                      # residual, model.py:180
+    mu = r.mean(-1, keepdim=True)
+    var = ((r - mu) ** 2).mean(-1, keepdim=True)                   # biased variance
+    rstd = torch.rsqrt(var + cfg.ln_eps)
+    xhat = (r - mu) * rstd
+    n = xhat * P["layer_norm.weight"] + P["layer_norm.bias"]
+    pre = n @ P["fc1.weight"].t() + P["fc1.bias"]                  # model.py:183
+    f = torch.relu(pre)
+    if masks is not None:                                          # model.py:184
+        sf = 1.0 / (1.0 - cfg.p_fc)
+        fd = f * (masks["fc"].to(dt) * sf)
+    else:
+        fd = f
+    z = fd.reshape(B, L * F)                                       # model.py:187
+    if L < cfg.max_length:                                         # zero-pad branch, :190-193
+        z = torch.cat([z, torch.zeros(B, (cfg.max_length - L) * F, dtype=dt)], dim=1)
+    u = z @ P["fc_output.weight"].t() + P["fc_output.bias"]        # model.py:196
+    y = u.clamp(0.0, 1.0).reshape(B, cfg.sheet_h, cfg.sheet_w)     # model.py:199-202
+    cache = dict(x=x, L=L, e=e, qh=qh, kh=kh, vh=vh, A=A, Ad=Ad, o=o, rstd=rstd, xhat=xhat,
+                 n=n, pre=pre, z=z, u=u, masks=masks)
+    return y, cache
+
+
+def sheet_backward(P, cache, du, cfg):
+    """Reverse of sheet_forward (what loss.backward() does, model.py:309); SURVEY.md App. A.
+
+    du: gradient w.r.t. the pre-clamp output u [B, pixels] (clamp mask already applied).
+    Returns dict of the 12 gradients.
+    """
+    c = cache
+    B = du.shape[0]
+    L, E, H, F = c["L"], cfg.embed_dim, cfg.heads, cfg.fc_dim
+    D = E // H
+    masks = c["masks"]
+    G = {}
+    G["fc_output.weight"] = du.t() @ c["z"]
+    G["fc_output.bias"] = du.sum(0)
+    dz = du @ P["fc_output.weight"]
+    dfd = dz[:, :L * F].reshape(B, L, F)
+    df = dfd
+    if masks is not None:
+        df = df * (masks["fc"].to(du.dtype) * (1.0 / (1.0 - cfg.p_fc)))
+    df = df * (c["pre"] > 0).to(du.dtype)                         # ReLU mask (threshold_backward)
+    G["fc1.weight"] = df.reshape(-1, F).t() @ c["n"].reshape(-1, E)
+    G["fc1.bias"] = df.reshape(-1, F).sum(0)
+    dn = df @ P["fc1.weight"]
+    G["layer_norm.weight"] = (dn * c["xhat"]).reshape(-1, E).sum(0)
+    G["layer_norm.bias"] = dn.reshape(-1, E).sum(0)
+    g = dn * P["layer_norm.weight"]
+    dr = (g - g.mean(-1, keepdim=True) - c["xhat"] * (g * c["xhat"]).mean(-1, keepdim=True)) * c["rstd"]
+    de = dr.clone()
+    da = dr
+    G["attention.out_proj.weight"] = da.reshape(-1, E).t() @ c["o"].reshape(-1, E)
+    G["attention.out_proj.bias"] = da.reshape(-1, E).sum(0)
+    do = (da @ P["attention.out_proj.weight"]).reshape(B, L, H, D).permute(0, 2, 1, 3)
+    dAd = do @ c["vh"].transpose(-1, -2)
+    dv = c["Ad"].transpose(-1, -2) @ do
+    dA = dAd
+    if masks is not None:
+        dA = dA * (masks["attn"].to(du.dtype) * (1.0 / (1.0 - cfg.p_attn)))
+    A = c["A"]
+    dS = A * (dA - (dA * A).sum(-1, keepdim=True))                 # softmax backward
+    scale = math.sqrt(1.0 / D)
+    dq = (dS @ c["kh"]) * scale
+    dk = dS.transpose(-1, -2) @ (c["qh"] * scale)
+
+    def merge(t):
+        return t.permute(0, 2, 1, 3).reshape(B, L, E)
+
+    dqkv = torch.cat([merge(dq), merge(dk), merge(dv)], dim=-1)
+    G["attention.in_proj_weight"] = dqkv.reshape(-1, 3 * E).t() @ c["e"].reshape(-1, E)
+    G["attention.in_proj_bias"] = dqkv.reshape(-1, 3 * E).sum(0)
+    de = de + dqkv @ P["attention.in_proj_weight"]
+    dP = torch.zeros_like(P["positional_encoding"])
+    dP[:L] = de.sum(0)
+    G["positional_encoding"] = dP
+    de0 = de
+    if masks is not None:
+        de0 = de0 * (masks["embed"].to(du.dtype) * (1.0 / (1.0 - cfg.p_embed)))
+    dEmb = torch.zeros_like(P["embedding.weight"])
+    dEmb.index_add_(0, c["x"].reshape(-1), de0.reshape(-1, E))     # embedding_dense_backward
+    G["embedding.weight"] = dEmb
+    return G
+
+
+# --------------------------------------------------------------------------- glyph MLP (C1-C4)
+def glyph_forward(P, x, font, cfg):
+    """Per-glyph MLP built from the reference's layer idioms: Embedding gather (model.py:136,167)
+    [+ font embedding], Linear+ReLU hidden layers (model.py:148,183), Linear + clamp output
+    (model.py:152-156,196-202).  Ancestor: learnings.md:3.  x,font: int64 [B]."""
+    h = P["embedding.weight"][x]
+    if cfg.n_fonts > 0:
+        h = h + P["font_embedding.weight"][font]
+    acts = [h]
+    nh = len(cfg.hidden)
+    pres = []
+    for i in range(nh):
+        pre = h @ P[f"fc{i + 1}.weight"].t() + P[f"fc{i + 1}.bias"]
+        pres.append(pre)
+        h = torch.relu(pre)
+        acts.append(h)
+    u = h @ P["fc_output.weight"].t() + P["fc_output.bias"]
+    y = u.clamp(0.0, 1.0).reshape(-1, cfg.out_h, cfg.out_w)
+    return y, dict(x=x, font=font, acts=acts, pres=pres, u=u)
+
+
+def glyph_backward(P, cache, du, cfg):
+    G = {}
+    acts, pres = cache["acts"], cache["pres"]
+    nh = len(cfg.hidden)
+    G["fc_output.weight"] = du.t() @ acts[nh]
+    G["fc_output.bias"] = du.sum(0)
+    d = du @ P["fc_output.weight"]
+    for i in reversed(range(nh)):
+        d = d * (pres[i] > 0).to(d.dtype)
+        G[f"fc{i + 1}.weight"] = d.t() @ acts[i]
+        G[f"fc{i + 1}.bias"] = d.sum(0)
+        d = d @ P[f"fc{i + 1}.weight"]
+    dEmb = torch.zeros_like(P["embedding.weight"])
+    dEmb.index_add_(0, cache["x"], d)
+    G["embedding.weight"] = dEmb
+    if cfg.n_fonts > 0:
+        dF = torch.zeros_like(P["font_embedding.weight"])
+        dF.index_add_(0, cache["font"], d)
+        G["font_embedding.weight"] = dF
+    return G
+
+
+# --------------------------------------------------------------------------- loss / optimiser
+def mse_loss_grad(u, target, total_elems=None):
+    """F.mse_loss(clamp(u,0,1), target) and its gradient w.r.t. u (model.py:156,268-270).
+    clamp passes gradient where 0 <= u <= 1 inclusive (torch clamp_backward).  total_elems
+    overrides the mean's denominator (global batch * pixels under data parallelism)."""
+    u2 = u.reshape(u.shape[0], -1)
+    t2 = target.reshape(u2.shape).to(u2.dtype)
+    n = float(total_elems if total_elems is not None else u2.numel())
+    y = u2.clamp(0.0, 1.0)
+    diff = y - t2
+    loss = (diff * diff).sum() / n
+    du = (2.0 / n) * diff * ((u2 >= 0) & (u2 <= 1)).to(u2.dtype)
+    return loss, du
+
+
+def adamw_step(p, g, m, v, t, lr=1e-3, beta1=0.9, beta2=0.99, eps=1e-8, wd=5e-4):
+    """One torch.optim.AdamW update (model.py:273; torch/optim/adamw.py single-tensor path):
+    decoupled decay, bias-corrected moments, denom = sqrt(v)/sqrt(1-b2^t) + eps.  t = 1,2,...
+    Returns new (p, m, v)."""
+    p = p * (1.0 - lr * wd)
+    m = beta1 * m + (1.0 - beta1) * g
+    v = beta2 * v + (1.0 - beta2) * g * g
+    bc1 = 1.0 - beta1 ** t
+    bc2 = 1.0 - beta2 ** t
+    denom = v.sqrt() / math.sqrt(bc2) + eps
+    p = p - (lr / bc1) * (m / denom)
+    return p, m, v
+
+
+def train_step(P, M, V, t, x, target, cfg, font=None, masks=None, lr=1e-3, beta1=0.9, beta2=0.99,
+               eps=1e-8, wd=5e-4):
+    """zero_grad -> forward -> MSE -> backward -> AdamW (model.py:292-310).  Returns
+    (loss, grads, newP, newM, newV)."""
+    if cfg.kind == "sheet":
+        _, cache = sheet_forward(P, x, cfg, masks)
+        loss, du = mse_loss_grad(cache["u"], target)
+        G = sheet_backward(P, cache, du, cfg)
+    else:
+        _, cache = glyph_forward(P, x, font, cfg)
+        loss, du = mse_loss_grad(cache["u"], target)
+        G = glyph_backward(P, cache, du, cfg)
+    nP, nM, nV = {}, {}, {}
+    for k in P:
+        nP[k], nM[k], nV[k] = adamw_step(P[k], G[k], M[k], V[k], t, lr, beta1, beta2, eps, wd)
+    return loss, G, nP, nM, nV
+
+
+# --------------------------------------------------------------------------- helpers.py twins
+def sheet_to_u8(arr):
+    """binary_array_to_image's quantisation: (a*255).astype(uint8) truncates (helpers.py:33)."""
+    import numpy as np
+    return (np.asarray(arr, dtype=np.float32) * 255).astype(np.uint8)

@@ -1,0 +1,222 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REFERENCE itself (imported from /root/reference).
+
+Run in the build container only (the reference never travels to the GPU box):
+    cd /root/repo && PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+Fixtures hold inputs and expected outputs only.  Weights are regenerated from the counter hash
+(ai_font_renderer_amd.synth.make_params) and loaded with load_state_dict, so no weight file is
+stored.  What is captured:
+  sheet_mini.npz  mini sheet model (8x24 sheet, max_length 10): eval outputs for L=10, L=6 (pad
+                  branch, model.py:190-193) and L=14 (truncate branch, model.py:163-164); train-mode
+                  loss + all 12 grads with dropout off and with injected dropout masks; 3 AdamW steps
+  sheet_r0.npz    the shipped model (80x240, L=100): eval outputs of the 15 test_strings
+                  (model.py:111-127) and a B=8 train-mode step: loss, 11 small grads in full,
+                  fc_output.weight.grad as row sums, column sums and 4096 hashed samples
+  helpers.npz     binary_array_to_image truncation (helpers.py:33), image_to_binary_array (helpers.py:121)
+                  on a 24-bit top-down BMP written per generate_font.ts:6-62
+"""
+import io
+import os
+import sys
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, "/root/reference")
+sys.dont_write_bytecode = True
+
+import torch  # noqa: E402
+import torch.nn.functional as F  # noqa: E402
+
+import model as ref  # noqa: E402  (the reference's model.py)
+import helpers as ref_helpers  # noqa: E402
+
+from ai_font_renderer_amd import synth  # noqa: E402
+from ai_font_renderer_amd.config import SheetConfig  # noqa: E402
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+torch.set_num_threads(8)
+
+
+def build_ref(cfg):
+    ref.SHEET_HEIGHT, ref.SHEET_WIDTH = cfg.sheet_h, cfg.sheet_w
+    m = ref.AttentionFontRenderer(max_length=cfg.max_length)
+    sd = {k: torch.from_numpy(v) for k, v in synth.make_params(cfg).items()}
+    m.load_state_dict(sd)
+    return m
+
+
+class InjectedDropout:
+    """Replace F.dropout (used by nn.Dropout and by multi_head_attention_forward) with supplied
+    keep masks, looked up by tensor shape."""
+
+    def __init__(self, masks_by_shape):
+        self.masks = masks_by_shape
+        self.calls = 0
+
+    def __enter__(self):
+        self.orig = F.dropout
+
+        def fake(input, p=0.5, training=True, inplace=False):
+            if not training or p == 0.0:
+                return input
+            mask = self.masks[tuple(input.shape)]
+            self.calls += 1
+            return input * (mask.to(input.dtype) * (1.0 / (1.0 - p)))
+
+        F.dropout = fake
+        torch.nn.functional.dropout = fake
+        return self
+
+    def __exit__(self, *a):
+        F.dropout = self.orig
+        torch.nn.functional.dropout = self.orig
+
+
+def grads_of(m):
+    return {k: p.grad.detach().clone().numpy() for k, p in m.named_parameters()}
+
+
+def train_grads(m, x, t, masks=None, cfg=None):
+    m.train()
+    m.zero_grad()
+    if masks is None:
+        m.embedding_dropout.p = 0.0
+        m.dropout1.p = 0.0
+        m.attention.dropout = 0.0
+        out = m(x)
+    else:
+        m.embedding_dropout.p = cfg.p_embed
+        m.dropout1.p = cfg.p_fc
+        m.attention.dropout = cfg.p_attn
+        B, L = x.shape[0], min(x.shape[1], cfg.max_length)
+        by_shape = {
+            (B, L, cfg.embed_dim): torch.from_numpy(masks["embed"]),
+            (B * cfg.heads, L, L): torch.from_numpy(masks["attn"]).reshape(B * cfg.heads, L, L),
+            (B, L, cfg.fc_dim): torch.from_numpy(masks["fc"]),
+        }
+        with InjectedDropout(by_shape) as inj:
+            out = m(x)
+        assert inj.calls == 3, inj.calls
+    loss = F.mse_loss(out, t.view(out.shape))
+    loss.backward()
+    return float(loss.item()), grads_of(m), out.detach().numpy()
+
+
+def mini():
+    cfg = SheetConfig(max_length=10, sheet_h=8, sheet_w=24)
+    m = build_ref(cfg)
+    strings = ["HELLO WORL", "AB CD", "ZZZZZZZZZZ", "Q W E R T ", "  MIX  UP "]
+    x10 = torch.from_numpy(synth.encode_strings(strings, 10))
+    x6 = x10[:, :6].contiguous()
+    x14 = torch.cat([x10, x10[:, :4]], dim=1).contiguous()
+    tgt = torch.from_numpy(synth.synth_sheet_targets(5, 8, 24, tensor_id=901).astype(np.float32) / 255.0)
+    fx = dict(x10=x10.numpy(), x6=x6.numpy(), x14=x14.numpy(), target_u8=synth.synth_sheet_targets(5, 8, 24, tensor_id=901))
+    m.eval()
+    with torch.no_grad():
+        fx["eval_y10"] = m(x10).numpy()
+        fx["eval_y6"] = m(x6).numpy()
+        fx["eval_y14"] = m(x14).numpy()
+    loss, g, _ = train_grads(m, x10, tgt)
+    fx["nodrop_loss"] = np.float32(loss)
+    for k, v in g.items():
+        fx["nodrop_grad/" + k] = v
+    loss6, g6, _ = train_grads(m, x6, tgt)
+    fx["nodrop6_loss"] = np.float32(loss6)
+    for k, v in g6.items():
+        fx["nodrop6_grad/" + k] = v
+    masks = synth.sheet_dropout_masks(cfg, 5, 10, seed=42, step=7)
+    lossd, gd, outd = train_grads(m, x10, tgt, masks=masks, cfg=cfg)
+    fx["drop_loss"] = np.float32(lossd)
+    fx["drop_y"] = outd
+    for k, v in gd.items():
+        fx["drop_grad/" + k] = v
+    # 3 AdamW steps, dropout off (model.py:273 hyper-parameters)
+    m = build_ref(cfg)
+    m.train()
+    m.embedding_dropout.p = 0.0
+    m.dropout1.p = 0.0
+    m.attention.dropout = 0.0
+    opt = torch.optim.AdamW(m.parameters(), lr=ref.LEARNING_RATE, weight_decay=ref.WEIGHT_DECAY, betas=(0.9, 0.99))
+    losses = []
+    for _ in range(3):
+        opt.zero_grad()
+        out = m(x10)
+        loss = F.mse_loss(out, tgt.view(out.shape))
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+    fx["adamw_losses"] = np.array(losses, dtype=np.float32)
+    for k, v in m.state_dict().items():
+        fx["adamw_param/" + k] = v.detach().numpy()
+    np.savez_compressed(os.path.join(OUT, "sheet_mini.npz"), **fx)
+    print("sheet_mini.npz", {k: np.asarray(v).shape for k, v in list(fx.items())[:8]})
+
+
+def r0():
+    cfg = SheetConfig()
+    m = build_ref(cfg)
+    x = torch.from_numpy(synth.encode_strings(ref.test_strings, cfg.max_length))   # helpers.py:57-59
+    fx = dict(test_x=x.numpy())
+    m.eval()
+    with torch.no_grad():
+        fx["test_eval_y"] = m(x).numpy()
+    strings = synth.dataset_strings(8)
+    xb = torch.from_numpy(synth.encode_strings(strings, cfg.max_length))
+    tu8 = synth.synth_sheet_targets(8, 80, 240, tensor_id=902)
+    tgt = torch.from_numpy(tu8.astype(np.float32) / 255.0)
+    loss, g, _ = train_grads(m, xb, tgt)
+    fx["train_x"] = xb.numpy()
+    fx["train_loss"] = np.float32(loss)
+    for k, v in g.items():
+        if k == "fc_output.weight":
+            fx["train_gradW_rowsum"] = v.sum(1)
+            fx["train_gradW_colsum"] = v.sum(0)
+            idx = (synth._counter(77, 4096, 42) % np.uint64(v.size)).astype(np.int64)
+            fx["train_gradW_idx"] = idx
+            fx["train_gradW_samples"] = v.reshape(-1)[idx]
+        else:
+            fx["train_grad/" + k] = v
+    np.savez_compressed(os.path.join(OUT, "sheet_r0.npz"), **fx)
+    print("sheet_r0.npz eval", fx["test_eval_y"].shape, "loss", loss)
+
+
+def bmp24_topdown(rgb):
+    """24-bit BGR top-down BMP bytes in the layout generate_font.ts:6-62 writes."""
+    import struct
+    h, w, _ = rgb.shape
+    row = (w * 3 + 3) // 4 * 4
+    data = bytearray()
+    for y in range(h):
+        line = bytearray(rgb[y, :, ::-1].tobytes())
+        line += b"\0" * (row - w * 3)
+        data += line
+    hdr = b"BM" + struct.pack("<IHHI", 54 + len(data), 0, 0, 54)
+    dib = struct.pack("<IiiHHIIiiII", 40, w, -h, 1, 24, 0, len(data), 0, 0, 0, 0)
+    return hdr + dib + bytes(data)
+
+
+def helpers_fx():
+    a = synth.hash_u01(903, 80 * 240).astype(np.float32).reshape(80, 240)
+    a[0, :5] = [0.0, 1.0, 0.999, 0.5, 254.5 / 255.0]
+    img = ref_helpers.binary_array_to_image(a)                    # helpers.py:20-44
+    u8 = np.array(img)
+    gray = synth.hash_u8(904, (80, 240))
+    rgb = np.stack([gray, gray, gray], axis=-1)
+    rgb2 = synth.hash_u8(905, (80, 240, 3))                       # coloured pixels go through PIL 'L' luma
+    with tempfile.TemporaryDirectory() as d:
+        p1, p2 = os.path.join(d, "1.bmp"), os.path.join(d, "2.bmp")
+        open(p1, "wb").write(bmp24_topdown(rgb))
+        open(p2, "wb").write(bmp24_topdown(rgb2))
+        f1 = ref_helpers.image_to_binary_array(p1)                 # helpers.py:107-123
+        f2 = ref_helpers.image_to_binary_array(p2)
+    np.savez_compressed(os.path.join(OUT, "helpers.npz"), arr=a, arr_u8=u8, gray=gray, gray_f32=f1, rgb=rgb2, rgb_f32=f2)
+    print("helpers.npz")
+
+
+if __name__ == "__main__":
+    mini()
+    helpers_fx()
+    r0()

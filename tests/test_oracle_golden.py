@@ -1,0 +1,140 @@
+"""CPU: pin the oracle (oracle/afr_oracle.py) against outputs of the reference itself
+(tests/golden/*.npz, produced by tests/golden/make_golden.py from /root/reference)."""
+import numpy as np
+import torch
+
+from .util import MINI, R0, load, maxabs, oracle, synth, tmasks, tparams
+
+
+def _t(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def test_mini_eval_all_length_branches():
+    fx = load("sheet_mini.npz")
+    P = tparams(MINI)
+    for key in ("10", "6", "14"):          # exact, zero-pad (model.py:190-193), truncate (model.py:163-164)
+        y, _ = oracle.sheet_forward(P, _t(fx["x" + key]), MINI)
+        assert maxabs(y.numpy(), fx["eval_y" + key]) < 2e-6, key
+
+
+def _check_grads(fx, prefix, G, tol):
+    for k, g in G.items():
+        ref = fx[prefix + k]
+        scale = max(1e-6, float(np.abs(ref).max()))
+        assert maxabs(g.numpy(), ref) / scale < tol, (k, maxabs(g.numpy(), ref), scale)
+
+
+def test_mini_train_grads_no_dropout():
+    fx = load("sheet_mini.npz")
+    P = tparams(MINI)
+    tgt = _t(fx["target_u8"].astype(np.float32) / 255.0)
+    for key, pre in (("x10", "nodrop"), ("x6", "nodrop6")):
+        _, cache = oracle.sheet_forward(P, _t(fx[key]), MINI)
+        loss, du = oracle.mse_loss_grad(cache["u"], tgt)
+        assert abs(float(loss) - float(fx[pre + "_loss"])) < 1e-6
+        _check_grads(fx, pre + "_grad/", oracle.sheet_backward(P, cache, du, MINI), 2e-5)
+
+
+def test_mini_train_grads_injected_dropout():
+    """The three dropouts (model.py:137,144,149) with the counter-hash masks injected into the
+    reference's F.dropout: same masks, same scaling, same order."""
+    fx = load("sheet_mini.npz")
+    P = tparams(MINI)
+    tgt = _t(fx["target_u8"].astype(np.float32) / 255.0)
+    masks = tmasks(synth.sheet_dropout_masks(MINI, 5, 10, seed=42, step=7))
+    y, cache = oracle.sheet_forward(P, _t(fx["x10"]), MINI, masks)
+    assert maxabs(y.numpy(), fx["drop_y"]) < 2e-6
+    loss, du = oracle.mse_loss_grad(cache["u"], tgt)
+    assert abs(float(loss) - float(fx["drop_loss"])) < 1e-6
+    _check_grads(fx, "drop_grad/", oracle.sheet_backward(P, cache, du, MINI), 2e-5)
+
+
+def test_mini_three_adamw_steps():
+    fx = load("sheet_mini.npz")
+    P = tparams(MINI)
+    M = {k: torch.zeros_like(v) for k, v in P.items()}
+    V = {k: torch.zeros_like(v) for k, v in P.items()}
+    tgt = _t(fx["target_u8"].astype(np.float32) / 255.0)
+    x = _t(fx["x10"])
+    for t in (1, 2, 3):
+        loss, _, P, M, V = oracle.train_step(P, M, V, t, x, tgt, MINI)
+        assert abs(float(loss) - float(fx["adamw_losses"][t - 1])) < 2e-6
+    E = MINI.embed_dim
+    for k in P:
+        got, ref = P[k].numpy(), fx["adamw_param/" + k]
+        if k == "attention.in_proj_bias":
+            # d(loss)/d(k-bias) is analytically 0 (softmax is shift invariant), so its gradient is
+            # rounding noise and Adam turns noise into +-lr steps: only bounded, never reproducible.
+            assert maxabs(got[E:2 * E], ref[E:2 * E]) < 3 * 1e-3 * 1.01
+            got, ref = np.delete(got, np.s_[E:2 * E]), np.delete(ref, np.s_[E:2 * E])
+        assert maxabs(got, ref) < 5e-6, k
+
+
+def test_r0_test_strings_eval():
+    """The shipped configuration on the reference's 15 test_strings (model.py:111-127)."""
+    fx = load("sheet_r0.npz")
+    P = tparams(R0)
+    y, _ = oracle.sheet_forward(P, _t(fx["test_x"]), R0)
+    assert maxabs(y.numpy(), fx["test_eval_y"]) < 5e-6
+
+
+def test_r0_train_step_grads():
+    fx = load("sheet_r0.npz")
+    P = tparams(R0)
+    tgt = _t(synth.synth_sheet_targets(8, 80, 240, tensor_id=902).astype(np.float32) / 255.0)
+    _, cache = oracle.sheet_forward(P, _t(fx["train_x"]), R0)
+    loss, du = oracle.mse_loss_grad(cache["u"], tgt)
+    assert abs(float(loss) - float(fx["train_loss"])) < 2e-6
+    G = oracle.sheet_backward(P, cache, du, R0)
+    gw = G.pop("fc_output.weight").numpy()
+    _check_grads(fx, "train_grad/", G, 5e-5)
+    assert maxabs(gw.sum(1), fx["train_gradW_rowsum"]) / np.abs(fx["train_gradW_rowsum"]).max() < 5e-5
+    assert maxabs(gw.sum(0), fx["train_gradW_colsum"]) / np.abs(fx["train_gradW_colsum"]).max() < 5e-5
+    s = gw.reshape(-1)[fx["train_gradW_idx"]]
+    assert maxabs(s, fx["train_gradW_samples"]) / np.abs(fx["train_gradW_samples"]).max() < 5e-5
+
+
+def test_oracle_backward_matches_autograd_fp64():
+    """Independent of the fixtures: the explicit backward equals autograd of the explicit forward."""
+    cfg = MINI
+    P = {k: v.double().requires_grad_(True) for k, v in tparams(cfg).items()}
+    x = _t(synth.encode_strings(["ABCDEFGH", "X Y Z"], 10))[:, :8]
+    masks = tmasks(synth.sheet_dropout_masks(cfg, 2, 8, seed=1, step=3))
+    tgt = torch.rand(2, 8, 24, dtype=torch.float64)
+    y, cache = oracle.sheet_forward(P, x, cfg, masks)
+    loss = ((y - tgt) ** 2).mean()
+    loss.backward()
+    with torch.no_grad():
+        l2, du = oracle.mse_loss_grad(cache["u"], tgt)
+        G = oracle.sheet_backward(P, cache, du, cfg)
+    assert abs(float(l2) - float(loss)) < 1e-12
+    for k in P:
+        assert maxabs(G[k].numpy(), P[k].grad.numpy()) < 1e-10, k
+
+
+def test_glyph_oracle_backward_matches_autograd_fp64():
+    from .util import GlyphConfig, glyph_inputs
+    cfg = GlyphConfig(hidden=(48, 40), out_h=4, out_w=6, n_fonts=2)
+    P = {k: v.double().requires_grad_(True) for k, v in tparams(cfg).items()}
+    x, font, t = glyph_inputs(cfg, 200)
+    x, font = _t(x), _t(font)
+    tgt = _t(t.astype(np.float64) / 255.0)
+    y, cache = oracle.glyph_forward(P, x, font, cfg)
+    loss = ((y - tgt) ** 2).mean()
+    loss.backward()
+    with torch.no_grad():
+        l2, du = oracle.mse_loss_grad(cache["u"], tgt)
+        G = oracle.glyph_backward(P, cache, du, cfg)
+    assert abs(float(l2) - float(loss)) < 1e-12
+    for k in P:
+        assert maxabs(G[k].numpy(), P[k].grad.numpy()) < 1e-10, k
+
+
+def test_text_generator_matches_survey_strings():
+    """generate_font.ts:164-199 restated; first strings for seeds 42..44."""
+    assert synth.lcg_text(42) == "P JAL WZ MQWPCDYYX EOGYVE MBANVV"
+    assert synth.lcg_text(43) == "GG U AJBHEQVVO ZFU TFI G PHRPSUL"
+    assert synth.lcg_text(44) == "YHS IYXCTW TBALZN YHXKESJ CHFW BM"
+    lens = [len(synth.lcg_text(42 + i)) for i in range(2000)]
+    assert min(lens) >= 10 and max(lens) <= 100
