@@ -1,0 +1,601 @@
+// afr_api.hip -- the C ABI of libafr.so (include/afr.h): plan construction, workspace carve-up and the
+// launch sequences of forward / loss / backward / AdamW for both model families.
+#include "afr_common.h"
+#include "../../include/afr.h"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+// --------------------------------------------------------------------------------- error plumbing
+static thread_local char g_err[512] = "";
+static int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+#define HIPCHK(expr)                                                                          \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess) return fail(AFR_EHIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+extern "C" int afr_version(void) { return AFR_VERSION; }
+extern "C" const char* afr_last_error(void) { return g_err; }
+
+// ------------------------------------------------------------------------------------------ plan
+struct Tensor {
+    std::string name;
+    int64_t off = 0, numel = 0;
+    int ndim = 0;
+    int64_t shape[4] = {0, 0, 0, 0};
+};
+
+struct ProfRec { int tag; hipEvent_t a, b; double flops, bytes; };
+
+struct afr_plan {
+    afr_config cfg;
+    std::vector<Tensor> params;
+    int64_t total = 0;
+    int act_bytes = 4;
+    // bound buffers
+    float *P = nullptr, *G = nullptr, *M = nullptr, *V = nullptr;
+    char* ws = nullptr;
+    size_t ws_bytes = 0, ws_need = 0;
+    // workspace offsets (bytes)
+    size_t o_shadow = 0, o_err = 0, o_loss = 0, o_u = 0, o_z = 0, o_dz = 0, o_slab_w = 0, o_slab_c = 0, o_slab_e = 0;
+    std::vector<size_t> o_act;     // glyph: activations h0..h_nh
+    size_t o_d[2] = {0, 0};        // glyph: ping-pong d buffers
+    size_t slab_w_elems = 0;
+    // glyph layer table
+    struct Layer { int N, K; int64_t w_off, b_off; };
+    std::vector<Layer> layers;
+    int64_t emb_off = 0, font_off = 0;
+    // sheet offsets
+    int64_t s_pos = 0, s_emb = 0, s_win = 0, s_bin = 0, s_wo = 0, s_bo = 0, s_g = 0, s_b = 0, s_w1 = 0, s_b1 = 0, s_wout = 0, s_bout = 0;
+    // state left by the last forward
+    const int64_t* last_x = nullptr;
+    const int64_t* last_font = nullptr;
+    int last_B = 0, last_L = 0, last_ldx = 0, last_training = 0;
+    uint64_t last_step = 0;
+    bool have_du = false;
+    // profiling
+    bool prof_on = false;
+    std::vector<ProfRec> prof;
+    std::vector<std::string> prof_tags;
+    std::vector<hipEvent_t> ev_pool;
+};
+
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+static void add_param(afr_plan* p, const char* name, std::initializer_list<int64_t> shape) {
+    Tensor t;
+    t.name = name;
+    t.ndim = (int)shape.size();
+    int64_t n = 1;
+    int i = 0;
+    for (int64_t s : shape) { t.shape[i++] = s; n *= s; }
+    t.numel = n;
+    t.off = p->total;
+    p->total += (n + 63) / 64 * 64;
+    p->params.push_back(t);
+}
+static int64_t off_of(const afr_plan* p, const char* name) {
+    for (const Tensor& t : p->params)
+        if (t.name == name) return t.off;
+    return -1;
+}
+
+static int choose_splitk(int M, int N, int K) {
+    const int tiles = ((M + 127) / 128) * ((N + 127) / 128);
+    int s = (512 + tiles - 1) / tiles;
+    const int maxs = K / 256 > 0 ? K / 256 : 1;
+    if (s > maxs) s = maxs;
+    if (s < 1) s = 1;
+    if (s > 64) s = 64;
+    return s;
+}
+
+extern "C" int afr_plan_create(const afr_config* c, afr_plan** out) {
+    if (!c || !out) return fail(AFR_EINVAL, "null argument");
+    if (c->dtype != AFR_F32 && c->dtype != AFR_BF16) return fail(AFR_EINVAL, "dtype must be AFR_F32 or AFR_BF16");
+    if (c->max_batch <= 0) return fail(AFR_EINVAL, "max_batch must be positive");
+    if (c->vocab <= 0 || c->embed_dim <= 0 || c->out_h <= 0 || c->out_w <= 0) return fail(AFR_EINVAL, "bad shape");
+    const int Pix = c->out_h * c->out_w;
+    if (Pix % 8) return fail(AFR_EUNSUPPORTED, "out_h*out_w must be a multiple of 8 (got %d)", Pix);
+    afr_plan* p = new afr_plan();
+    p->cfg = *c;
+    p->act_bytes = c->dtype == AFR_BF16 ? 2 : 4;
+    const int E = c->embed_dim;
+    const size_t B = (size_t)c->max_batch;
+    const size_t ab = (size_t)p->act_bytes;
+    size_t off = 0;
+    auto carve = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+
+    if (c->kind == AFR_KIND_SHEET) {
+        if (E != 32 || c->heads != 4 || c->fc_dim != 64)
+            { delete p; return fail(AFR_EUNSUPPORTED, "sheet front end is built for embed_dim 32, 4 heads, fc_dim 64 (model.py:79,81,148)"); }
+        if (c->max_length <= 0 || c->max_length > 120) { delete p; return fail(AFR_EUNSUPPORTED, "max_length must be in 1..120 (one string's state must fit 160 KiB of LDS)"); }
+        const int L = c->max_length, F = c->fc_dim;
+        add_param(p, "positional_encoding", {L, E});
+        add_param(p, "embedding.weight", {c->vocab, E});
+        add_param(p, "attention.in_proj_weight", {3 * E, E});
+        add_param(p, "attention.in_proj_bias", {3 * E});
+        add_param(p, "attention.out_proj.weight", {E, E});
+        add_param(p, "attention.out_proj.bias", {E});
+        add_param(p, "layer_norm.weight", {E});
+        add_param(p, "layer_norm.bias", {E});
+        add_param(p, "fc1.weight", {F, E});
+        add_param(p, "fc1.bias", {F});
+        add_param(p, "fc_output.weight", {Pix, (int64_t)L * F});
+        add_param(p, "fc_output.bias", {Pix});
+        p->s_pos = off_of(p, "positional_encoding"); p->s_emb = off_of(p, "embedding.weight");
+        p->s_win = off_of(p, "attention.in_proj_weight"); p->s_bin = off_of(p, "attention.in_proj_bias");
+        p->s_wo = off_of(p, "attention.out_proj.weight"); p->s_bo = off_of(p, "attention.out_proj.bias");
+        p->s_g = off_of(p, "layer_norm.weight"); p->s_b = off_of(p, "layer_norm.bias");
+        p->s_w1 = off_of(p, "fc1.weight"); p->s_b1 = off_of(p, "fc1.bias");
+        p->s_wout = off_of(p, "fc_output.weight"); p->s_bout = off_of(p, "fc_output.bias");
+        const size_t Kz = (size_t)L * F;
+        if (c->dtype == AFR_BF16) p->o_shadow = carve((size_t)p->total * 2);
+        p->o_err = carve(256);
+        p->o_loss = carve(1024 * sizeof(float));
+        p->o_z = carve(B * Kz * ab);
+        p->o_u = carve(B * Pix * ab);
+        p->o_dz = carve(B * Kz * ab);
+        const int sk = choose_splitk(Pix, (int)Kz, (int)B);
+        p->slab_w_elems = sk > 1 ? (size_t)sk * Pix * Kz : 0;
+        p->o_slab_w = carve(p->slab_w_elems * sizeof(float));
+        p->o_slab_c = carve((size_t)afr_colsum_splits((long long)B) * Pix * sizeof(float));
+        p->o_slab_e = carve((size_t)afr_sheet_blocks((int)B) * (size_t)p->s_wout * sizeof(float));
+    } else if (c->kind == AFR_KIND_GLYPH) {
+        if (c->n_hidden < 0 || c->n_hidden > AFR_MAX_HIDDEN) { delete p; return fail(AFR_EINVAL, "n_hidden out of range"); }
+        if (E % 8) { delete p; return fail(AFR_EUNSUPPORTED, "embed_dim must be a multiple of 8"); }
+        for (int i = 0; i < c->n_hidden; ++i)
+            if (c->hidden[i] <= 0 || c->hidden[i] % 8) { delete p; return fail(AFR_EUNSUPPORTED, "hidden widths must be positive multiples of 8"); }
+        add_param(p, "embedding.weight", {c->vocab, E});
+        if (c->n_fonts > 0) add_param(p, "font_embedding.weight", {c->n_fonts, E});
+        int k = E;
+        char nm[64];
+        for (int i = 0; i < c->n_hidden; ++i) {
+            snprintf(nm, sizeof nm, "fc%d.weight", i + 1);
+            add_param(p, nm, {c->hidden[i], k});
+            afr_plan::Layer ly; ly.N = c->hidden[i]; ly.K = k; ly.w_off = p->params.back().off;
+            snprintf(nm, sizeof nm, "fc%d.bias", i + 1);
+            add_param(p, nm, {c->hidden[i]});
+            ly.b_off = p->params.back().off;
+            p->layers.push_back(ly);
+            k = c->hidden[i];
+        }
+        add_param(p, "fc_output.weight", {Pix, k});
+        afr_plan::Layer ly; ly.N = Pix; ly.K = k; ly.w_off = p->params.back().off;
+        add_param(p, "fc_output.bias", {Pix});
+        ly.b_off = p->params.back().off;
+        p->layers.push_back(ly);
+        p->emb_off = off_of(p, "embedding.weight");
+        p->font_off = c->n_fonts > 0 ? off_of(p, "font_embedding.weight") : -1;
+        if (c->dtype == AFR_BF16) p->o_shadow = carve((size_t)p->total * 2);
+        p->o_err = carve(256);
+        p->o_loss = carve(1024 * sizeof(float));
+        size_t maxw = (size_t)E, maxn = 0;
+        p->o_act.push_back(carve(B * E * ab));
+        for (int i = 0; i < c->n_hidden; ++i) {
+            p->o_act.push_back(carve(B * (size_t)c->hidden[i] * ab));
+            if ((size_t)c->hidden[i] > maxw) maxw = (size_t)c->hidden[i];
+        }
+        p->o_u = carve(B * Pix * ab);
+        p->o_d[0] = carve(B * maxw * ab);
+        p->o_d[1] = carve(B * maxw * ab);
+        size_t slab = 0;
+        for (const auto& l : p->layers) {
+            const int sk = choose_splitk(l.N, l.K, (int)B);
+            if (sk > 1 && (size_t)sk * l.N * l.K > slab) slab = (size_t)sk * l.N * l.K;
+            if ((size_t)l.N > maxn) maxn = (size_t)l.N;
+        }
+        p->slab_w_elems = slab;
+        p->o_slab_w = carve(slab * sizeof(float));
+        p->o_slab_c = carve((size_t)afr_colsum_splits((long long)B) * maxn * sizeof(float));
+        p->o_slab_e = carve((size_t)afr_embed_bwd_blocks((int)B) * (size_t)(c->vocab + c->n_fonts) * E * sizeof(float));
+    } else {
+        delete p;
+        return fail(AFR_EINVAL, "unknown model kind %d", c->kind);
+    }
+    p->ws_need = off;
+    *out = p;
+    return AFR_OK;
+}
+
+extern "C" int afr_plan_destroy(afr_plan* p) {
+    if (!p) return AFR_OK;
+    for (hipEvent_t e : p->ev_pool) (void)hipEventDestroy(e);
+    for (auto& r : p->prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    delete p;
+    return AFR_OK;
+}
+
+extern "C" int64_t afr_param_elems(const afr_plan* p) { return p ? p->total : 0; }
+extern "C" int afr_param_count(const afr_plan* p) { return p ? (int)p->params.size() : 0; }
+extern "C" int afr_param_info(const afr_plan* p, int i, char* name, int cap, int64_t* offset, int64_t* numel,
+                              int32_t* ndim, int64_t shape[4]) {
+    if (!p || i < 0 || i >= (int)p->params.size()) return fail(AFR_EINVAL, "parameter index out of range");
+    const Tensor& t = p->params[i];
+    if (name && cap > 0) { strncpy(name, t.name.c_str(), cap - 1); name[cap - 1] = 0; }
+    if (offset) *offset = t.off;
+    if (numel) *numel = t.numel;
+    if (ndim) *ndim = t.ndim;
+    if (shape) for (int k = 0; k < 4; ++k) shape[k] = t.shape[k];
+    return AFR_OK;
+}
+extern "C" size_t afr_workspace_bytes(const afr_plan* p) { return p ? p->ws_need : 0; }
+
+extern "C" int afr_bind(afr_plan* p, float* params, float* grads, float* m, float* v, void* ws, size_t ws_bytes) {
+    if (!p || !params || !ws) return fail(AFR_EINVAL, "params and workspace are required");
+    if (ws_bytes < p->ws_need) return fail(AFR_EINVAL, "workspace too small: %zu < %zu", ws_bytes, p->ws_need);
+    if (((uintptr_t)params | (uintptr_t)grads | (uintptr_t)m | (uintptr_t)v | (uintptr_t)ws) & 255)
+        return fail(AFR_EINVAL, "buffers must be 256-byte aligned");
+    p->P = params; p->G = grads; p->M = m; p->V = v;
+    p->ws = (char*)ws; p->ws_bytes = ws_bytes;
+    p->have_du = false;
+    return AFR_OK;
+}
+
+// ---------------------------------------------------------------------------------- profiling
+static hipEvent_t ev_get(afr_plan* p) {
+    if (!p->ev_pool.empty()) { hipEvent_t e = p->ev_pool.back(); p->ev_pool.pop_back(); return e; }
+    hipEvent_t e;
+    (void)hipEventCreate(&e);
+    return e;
+}
+static int tag_id(afr_plan* p, const char* tag) {
+    for (size_t i = 0; i < p->prof_tags.size(); ++i)
+        if (p->prof_tags[i] == tag) return (int)i;
+    p->prof_tags.push_back(tag);
+    return (int)p->prof_tags.size() - 1;
+}
+struct ProfScope {
+    afr_plan* p; hipStream_t s; ProfRec r; bool on;
+    ProfScope(afr_plan* p_, hipStream_t s_, const char* tag, double flops, double bytes) : p(p_), s(s_), on(p_->prof_on) {
+        if (!on) return;
+        r.tag = tag_id(p, tag); r.flops = flops; r.bytes = bytes; r.a = ev_get(p); r.b = ev_get(p);
+        (void)hipEventRecord(r.a, s);
+    }
+    ~ProfScope() { if (on) { (void)hipEventRecord(r.b, s); p->prof.push_back(r); } }
+};
+extern "C" int afr_profile_dominant(afr_plan* p, int enable) {
+    if (!p) return fail(AFR_EINVAL, "null plan");
+    for (auto& r : p->prof) { p->ev_pool.push_back(r.a); p->ev_pool.push_back(r.b); }
+    p->prof.clear();
+    p->prof_on = enable != 0;
+    return AFR_OK;
+}
+extern "C" int afr_profile_read(afr_plan* p, char* name, int cap, double* avg_ms, int64_t* launches, double* flops,
+                                double* bytes) {
+    if (!p) return fail(AFR_EINVAL, "null plan");
+    if (p->prof.empty()) return fail(AFR_ESTATE, "no profiled launches recorded");
+    std::vector<double> tot(p->prof_tags.size(), 0.0), fl(p->prof_tags.size(), 0.0), by(p->prof_tags.size(), 0.0);
+    std::vector<int64_t> cnt(p->prof_tags.size(), 0);
+    for (auto& r : p->prof) {
+        HIPCHK(hipEventSynchronize(r.b));
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, r.a, r.b));
+        tot[r.tag] += ms; fl[r.tag] += r.flops; by[r.tag] += r.bytes; cnt[r.tag]++;
+    }
+    size_t best = 0;
+    for (size_t i = 1; i < tot.size(); ++i) if (tot[i] > tot[best]) best = i;
+    if (name && cap > 0) { strncpy(name, p->prof_tags[best].c_str(), cap - 1); name[cap - 1] = 0; }
+    if (avg_ms) *avg_ms = tot[best] / (double)cnt[best];
+    if (launches) *launches = cnt[best];
+    if (flops) *flops = fl[best] / (double)cnt[best];
+    if (bytes) *bytes = by[best] / (double)cnt[best];
+    return AFR_OK;
+}
+
+// ------------------------------------------------------------------------------------ helpers
+static inline const void* weight_ptr(const afr_plan* p, int64_t off) {
+    if (p->cfg.dtype == AFR_BF16) return p->ws + p->o_shadow + (size_t)off * 2;
+    return p->P + off;
+}
+static int run_gemm(afr_plan* p, hipStream_t s, int flags, const void* A, const void* B, void* C, const float* bias,
+                    const void* aux, int M, int N, int K, int lda, int ldb, int ldc, int ldaux, int splitk,
+                    long long slab_stride) {
+    GemmParams g;
+    g.A = A; g.B = B; g.C = C; g.bias = bias; g.aux = aux;
+    g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldaux = ldaux;
+    g.flags = flags; g.splitk = splitk; g.slab_stride = slab_stride;
+    const double eb = p->cfg.dtype == AFR_BF16 ? 2.0 : 4.0;
+    const double ob = (flags & AFR_GEMM_OUT_BF16) ? 2.0 : 4.0;
+    ProfScope ps(p, s, afr_gemm_kernel_name(p->cfg.dtype, flags), 2.0 * M * (double)N * K,
+                 eb * ((double)M * K + (double)N * K) + ob * (double)M * N * splitk);
+    HIPCHK(afr_launch_gemm(p->cfg.dtype, g, s));
+    return AFR_OK;
+}
+// dW[N][K] = dy[B][N]^T . a[B][K], reduced over the batch; split-K partial slabs when the output is small
+static int run_dw(afr_plan* p, hipStream_t s, const void* dy, const void* a, int Bn, int N, int K, float* Gw) {
+    const int sk = choose_splitk(N, K, Bn);
+    const int fl = AFR_GEMM_A_KSTRIDED | AFR_GEMM_B_KSTRIDED;
+    if (sk == 1) return run_gemm(p, s, fl, dy, a, Gw, nullptr, nullptr, N, K, Bn, N, K, K, 0, 1, 0);
+    float* slabs = (float*)(p->ws + p->o_slab_w);
+    if ((size_t)sk * N * K > p->slab_w_elems) return fail(AFR_ESTATE, "split-K slab space too small");
+    int rc = run_gemm(p, s, fl, dy, a, slabs, nullptr, nullptr, N, K, Bn, N, K, K, 0, sk, (long long)N * K);
+    if (rc) return rc;
+    ProfScope ps(p, s, "reduce_slabs", 0.0, 4.0 * (double)N * K * (sk + 1));
+    HIPCHK(afr_launch_reduce(Gw, slabs, sk, (long long)N * K, (long long)N * K, 1.f, 0, s));
+    return AFR_OK;
+}
+static int run_db(afr_plan* p, hipStream_t s, const void* dy, int Bn, int N, float* Gb) {
+    float* slabs = (float*)(p->ws + p->o_slab_c);
+    const int sp = afr_colsum_splits(Bn);
+    ProfScope ps(p, s, "colsum+reduce", 0.0, (double)p->act_bytes * Bn * N);
+    HIPCHK(afr_launch_colsum(p->cfg.dtype, dy, Bn, N, N, slabs, s));
+    HIPCHK(afr_launch_reduce(Gb, slabs, sp, N, N, 1.f, 0, s));
+    return AFR_OK;
+}
+
+extern "C" int afr_sync_params(afr_plan* p, void* stream) {
+    if (!p || !p->P) return fail(AFR_ESTATE, "plan has no bound parameters");
+    if (p->cfg.dtype != AFR_BF16) return AFR_OK;
+    HIPCHK(afr_launch_f32_to_bf16(p->P, (bf16_t*)(p->ws + p->o_shadow), p->total, (hipStream_t)stream));
+    return AFR_OK;
+}
+
+static SheetDrop make_drop(const afr_plan* p, int training, uint64_t step) {
+    SheetDrop d;
+    const afr_config& c = p->cfg;
+    d.training = training;
+    d.key_e = afr_dropout_key(c.seed, step, AFR_STREAM_EMBED, (uint64_t)c.rank);
+    d.key_a = afr_dropout_key(c.seed, step, AFR_STREAM_ATTN, (uint64_t)c.rank);
+    d.key_f = afr_dropout_key(c.seed, step, AFR_STREAM_FC, (uint64_t)c.rank);
+    d.thr_e = afr_keep_threshold(1.f - c.p_embed);
+    d.thr_a = afr_keep_threshold(1.f - c.p_attn);
+    d.thr_f = afr_keep_threshold(1.f - c.p_fc);
+    d.sc_e = 1.f / (1.f - c.p_embed);
+    d.sc_a = 1.f / (1.f - c.p_attn);
+    d.sc_f = 1.f / (1.f - c.p_fc);
+    return d;
+}
+static SheetParams sheet_params(const afr_plan* p) {
+    SheetParams sp;
+    sp.pos = p->P + p->s_pos; sp.emb = p->P + p->s_emb; sp.w_in = p->P + p->s_win; sp.b_in = p->P + p->s_bin;
+    sp.w_o = p->P + p->s_wo; sp.b_o = p->P + p->s_bo; sp.ln_g = p->P + p->s_g; sp.ln_b = p->P + p->s_b;
+    sp.w1 = p->P + p->s_w1; sp.b1 = p->P + p->s_b1;
+    return sp;
+}
+
+// ------------------------------------------------------------------------------------- forward
+extern "C" int afr_forward(afr_plan* p, const int64_t* x, const int64_t* font, int B, int L, float* y, int training,
+                           uint64_t step, void* stream) {
+    if (!p || !p->P) return fail(AFR_ESTATE, "plan has no bound parameters");
+    if (!x) return fail(AFR_EINVAL, "x is null");
+    if (B <= 0 || B > p->cfg.max_batch) return fail(AFR_EINVAL, "batch %d outside 1..max_batch=%d", B, p->cfg.max_batch);
+    hipStream_t s = (hipStream_t)stream;
+    const afr_config& c = p->cfg;
+    const int Pix = c.out_h * c.out_w;
+    const int ob = c.dtype == AFR_BF16 ? AFR_GEMM_OUT_BF16 : 0;
+    uint32_t* err = (uint32_t*)(p->ws + p->o_err);
+    void* u = p->ws + p->o_u;
+    if (c.kind == AFR_KIND_SHEET) {
+        if (L <= 0) return fail(AFR_EINVAL, "sequence length must be positive");
+        const int Lc = L < c.max_length ? L : c.max_length;               // model.py:163-164
+        SheetDims d{Lc, c.max_length, c.embed_dim, c.heads, c.fc_dim, c.vocab};
+        void* z = p->ws + p->o_z;
+        {
+            ProfScope ps(p, s, "sheet_fwd", 0.0, 0.0);
+            HIPCHK(afr_launch_sheet_fwd(c.dtype, d, sheet_params(p), make_drop(p, training, step), x, L, B, z, c.ln_eps, err, s));
+        }
+        const int Kz = c.max_length * c.fc_dim;
+        int rc = run_gemm(p, s, AFR_GEMM_BIAS | ob, z, weight_ptr(p, p->s_wout), u, p->P + p->s_bout, nullptr, B, Pix, Kz,
+                          Kz, Kz, Pix, 0, 1, 0);
+        if (rc) return rc;
+        p->last_L = Lc;
+        p->last_ldx = L;
+    } else {
+        if (c.n_fonts > 0 && !font) return fail(AFR_EINVAL, "font ids are required when n_fonts > 0");
+        void* h = p->ws + p->o_act[0];
+        {
+            ProfScope ps(p, s, "glyph_embed", 0.0, 0.0);
+            HIPCHK(afr_launch_glyph_embed(c.dtype, p->P + p->emb_off, c.n_fonts > 0 ? p->P + p->font_off : nullptr, x, font, B,
+                                          c.embed_dim, c.vocab, c.n_fonts, h, err, s));
+        }
+        const int nl = (int)p->layers.size();
+        for (int i = 0; i < nl; ++i) {
+            const auto& l = p->layers[i];
+            const bool last = (i == nl - 1);
+            void* outp = last ? u : (void*)(p->ws + p->o_act[i + 1]);
+            int rc = run_gemm(p, s, AFR_GEMM_BIAS | (last ? 0 : AFR_GEMM_RELU) | ob, h, weight_ptr(p, l.w_off), outp,
+                              p->P + l.b_off, nullptr, B, l.N, l.K, l.K, l.K, l.N, 0, 1, 0);
+            if (rc) return rc;
+            h = outp;
+        }
+        p->last_L = 1;
+    }
+    if (y) {
+        ProfScope ps(p, s, "clamp_out", 0.0, 0.0);
+        HIPCHK(afr_launch_clamp_out(c.dtype, u, y, (long long)B * Pix, s));
+    }
+    p->last_x = x; p->last_font = font; p->last_B = B; p->last_training = training; p->last_step = step;
+    p->have_du = false;
+    return AFR_OK;
+}
+
+// --------------------------------------------------------------------------------- loss + grad
+extern "C" int afr_loss_grad(afr_plan* p, const void* target, int tdtype, int B, int64_t mean_elems, float* loss_accum,
+                             void* stream) {
+    if (!p || !p->P) return fail(AFR_ESTATE, "plan has no bound parameters");
+    if (!target || !loss_accum) return fail(AFR_EINVAL, "target and loss_accum are required");
+    if (B != p->last_B) return fail(AFR_ESTATE, "loss_grad batch %d does not match the last forward (%d)", B, p->last_B);
+    if (tdtype != AFR_TARGET_U8 && tdtype != AFR_TARGET_F32) return fail(AFR_EINVAL, "bad target dtype");
+    if (mean_elems <= 0) return fail(AFR_EINVAL, "mean_elems must be positive");
+    hipStream_t s = (hipStream_t)stream;
+    const int Pix = p->cfg.out_h * p->cfg.out_w;
+    void* u = p->ws + p->o_u;
+    const double tb = tdtype == AFR_TARGET_U8 ? 1.0 : 4.0;
+    ProfScope ps(p, s, "mse_grad", 0.0, (double)B * Pix * (2.0 * p->act_bytes + tb));
+    HIPCHK(afr_launch_mse_grad(p->cfg.dtype, u, target, tdtype, u, B, Pix, mean_elems, loss_accum,
+                               (float*)(p->ws + p->o_loss), s));
+    p->have_du = true;
+    return AFR_OK;
+}
+
+// ------------------------------------------------------------------------------------ backward
+extern "C" int afr_backward(afr_plan* p, void* stream) {
+    if (!p || !p->P || !p->G) return fail(AFR_ESTATE, "plan has no bound parameter/gradient buffers");
+    if (!p->have_du) return fail(AFR_ESTATE, "afr_backward needs afr_forward + afr_loss_grad first");
+    hipStream_t s = (hipStream_t)stream;
+    const afr_config& c = p->cfg;
+    const int B = p->last_B, Pix = c.out_h * c.out_w;
+    const int ob = c.dtype == AFR_BF16 ? AFR_GEMM_OUT_BF16 : 0;
+    void* du = p->ws + p->o_u;
+    int rc;
+    if (c.kind == AFR_KIND_SHEET) {
+        const int Kz = c.max_length * c.fc_dim;
+        void* z = p->ws + p->o_z;
+        void* dz = p->ws + p->o_dz;
+        if ((rc = run_dw(p, s, du, z, B, Pix, Kz, p->G + p->s_wout))) return rc;
+        if ((rc = run_db(p, s, du, B, Pix, p->G + p->s_bout))) return rc;
+        if ((rc = run_gemm(p, s, AFR_GEMM_B_KSTRIDED | ob, du, weight_ptr(p, p->s_wout), dz, nullptr, nullptr, B, Kz, Pix, Pix,
+                           Kz, Kz, 0, 1, 0))) return rc;
+        SheetDims d{p->last_L, c.max_length, c.embed_dim, c.heads, c.fc_dim, c.vocab};
+        float* slabs = (float*)(p->ws + p->o_slab_e);
+        // a slab is laid out like the flat buffer's first s_wout floats: the 10 small tensors (pos .. fc1.bias)
+        SheetSlabOff so{(int)p->s_pos, (int)p->s_emb, (int)p->s_win, (int)p->s_bin, (int)p->s_wo, (int)p->s_bo, (int)p->s_g,
+                        (int)p->s_b, (int)p->s_w1, (int)p->s_b1, (int)p->s_wout};
+        {
+            ProfScope ps(p, s, "sheet_bwd", 0.0, 0.0);
+            HIPCHK(afr_launch_sheet_bwd(c.dtype, d, sheet_params(p), make_drop(p, p->last_training, p->last_step), p->last_x,
+                                        p->last_ldx, B, dz, c.ln_eps, slabs, so, s));
+            HIPCHK(afr_launch_reduce(p->G, slabs, afr_sheet_blocks(B), (long long)so.total, (long long)so.total, 1.f, 0, s));
+        }
+    } else {
+        const int nl = (int)p->layers.size();
+        const void* dy = du;
+        int pp = 0;
+        for (int i = nl - 1; i >= 0; --i) {
+            const auto& l = p->layers[i];
+            const void* a = p->ws + p->o_act[i];
+            if ((rc = run_dw(p, s, dy, a, B, l.N, l.K, p->G + l.w_off))) return rc;
+            if ((rc = run_db(p, s, dy, B, l.N, p->G + l.b_off))) return rc;
+            void* dx = p->ws + p->o_d[pp];
+            const int fl = AFR_GEMM_B_KSTRIDED | ob | (i > 0 ? AFR_GEMM_RELU_MASK : 0);
+            if ((rc = run_gemm(p, s, fl, dy, weight_ptr(p, l.w_off), dx, nullptr, i > 0 ? a : nullptr, B, l.K, l.N, l.N, l.K, l.K,
+                               l.K, 1, 0))) return rc;
+            dy = dx;
+            pp ^= 1;
+        }
+        float* slabs = (float*)(p->ws + p->o_slab_e);
+        const int blocks = afr_embed_bwd_blocks(B);
+        const long long rows = c.vocab + c.n_fonts;
+        {
+            ProfScope ps(p, s, "glyph_embed_bwd", 0.0, 0.0);
+            HIPCHK(afr_launch_glyph_embed_bwd(c.dtype, dy, p->last_x, p->last_font, B, c.embed_dim, c.vocab, c.n_fonts, slabs, s));
+            const long long stride = rows * c.embed_dim;
+            HIPCHK(afr_launch_reduce(p->G + p->emb_off, slabs, blocks, stride, (long long)c.vocab * c.embed_dim, 1.f, 0, s));
+            if (c.n_fonts > 0)
+                HIPCHK(afr_launch_reduce(p->G + p->font_off, slabs + (size_t)c.vocab * c.embed_dim, blocks, stride,
+                                         (long long)c.n_fonts * c.embed_dim, 1.f, 0, s));
+        }
+    }
+    p->have_du = false;
+    return AFR_OK;
+}
+
+// --------------------------------------------------------------------------------------- AdamW
+extern "C" int afr_adamw_step(afr_plan* p, float lr, float b1, float b2, float eps, float wd, int64_t t, float gscale,
+                              void* stream) {
+    if (!p || !p->P || !p->G || !p->M || !p->V) return fail(AFR_ESTATE, "AdamW needs params, grads and both moments bound");
+    if (t < 1) return fail(AFR_EINVAL, "t starts at 1");
+    hipStream_t s = (hipStream_t)stream;
+    const float bc1 = (float)(1.0 - std::pow((double)b1, (double)t));
+    const float bc2 = (float)(1.0 - std::pow((double)b2, (double)t));
+    bf16_t* shadow = p->cfg.dtype == AFR_BF16 ? (bf16_t*)(p->ws + p->o_shadow) : nullptr;
+    ProfScope ps(p, s, "adamw", 0.0, (double)p->total * (shadow ? 30.0 : 28.0));
+    HIPCHK(afr_launch_adamw(p->P, p->G, p->M, p->V, shadow, p->total, lr, b1, b2, eps, wd, bc1, bc2, gscale, s));
+    return AFR_OK;
+}
+
+extern "C" int afr_train_step(afr_plan* p, const int64_t* x, const int64_t* font, const void* target, int tdtype, int B,
+                              int L, int64_t mean_elems, float* loss_accum, uint64_t step, int do_step, float lr, float b1,
+                              float b2, float eps, float wd, int64_t t, void* stream) {
+    int rc;
+    if ((rc = afr_forward(p, x, font, B, L, nullptr, 1, step, stream))) return rc;
+    if ((rc = afr_loss_grad(p, target, tdtype, B, mean_elems, loss_accum, stream))) return rc;
+    if ((rc = afr_backward(p, stream))) return rc;
+    if (do_step && (rc = afr_adamw_step(p, lr, b1, b2, eps, wd, t, 1.f, stream))) return rc;
+    return AFR_OK;
+}
+
+extern "C" int afr_error_flags(afr_plan* p, void* stream, uint32_t* out) {
+    if (!p || !p->ws || !out) return fail(AFR_EINVAL, "plan must be bound and out non-null");
+    hipStream_t s = (hipStream_t)stream;
+    HIPCHK(hipMemcpyAsync(out, p->ws + p->o_err, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return AFR_OK;
+}
+
+extern "C" int afr_debug_copy(afr_plan* p, int which, void* dst, size_t cap, size_t* bytes_out, void* stream) {
+    if (!p || !p->ws || !dst) return fail(AFR_EINVAL, "plan must be bound and dst non-null");
+    if (p->last_B <= 0) return fail(AFR_ESTATE, "no forward has run yet");
+    const afr_config& c = p->cfg;
+    const size_t B = (size_t)p->last_B, ab = (size_t)p->act_bytes;
+    size_t off = 0, bytes = 0;
+    if (which == AFR_BUF_U) { off = p->o_u; bytes = B * c.out_h * c.out_w * ab; }
+    else if (which == AFR_BUF_Z && c.kind == AFR_KIND_SHEET) { off = p->o_z; bytes = B * c.max_length * c.fc_dim * ab; }
+    else if (which == AFR_BUF_DZ && c.kind == AFR_KIND_SHEET) { off = p->o_dz; bytes = B * c.max_length * c.fc_dim * ab; }
+    else if (which >= AFR_BUF_ACT && c.kind == AFR_KIND_GLYPH && which - AFR_BUF_ACT < (int)p->o_act.size()) {
+        const int i = which - AFR_BUF_ACT;
+        off = p->o_act[i];
+        bytes = B * (size_t)(i == 0 ? c.embed_dim : c.hidden[i - 1]) * ab;
+    } else return fail(AFR_EINVAL, "no such buffer %d for this model kind", which);
+    if (bytes > cap) return fail(AFR_EINVAL, "destination too small: %zu < %zu", cap, bytes);
+    HIPCHK(hipMemcpyAsync(dst, p->ws + off, bytes, hipMemcpyDefault, (hipStream_t)stream));
+    if (bytes_out) *bytes_out = bytes;
+    return AFR_OK;
+}
+
+// --------------------------------------------------------------------------- single-kernel ops
+extern "C" int afr_op_gemm(int dtype, int flags, const void* A, const void* B, void* C, const float* bias, const void* aux,
+                           int M, int N, int K, int lda, int ldb, int ldc, int ldaux, int splitk, void* stream) {
+    if (!A || !B || !C) return fail(AFR_EINVAL, "null operand");
+    if (M <= 0 || N <= 0 || K <= 0 || splitk < 1) return fail(AFR_EINVAL, "bad GEMM extents");
+    const int v = dtype == AFR_BF16 ? 8 : 4;
+    const bool ak = flags & AFR_GEMM_A_KSTRIDED, bk = flags & AFR_GEMM_B_KSTRIDED;
+    if ((ak ? M : K) % v || (bk ? N : K) % v || lda % v || ldb % v || N % 4 || ldc % 4)
+        return fail(AFR_EUNSUPPORTED, "contiguous extents and leading dimensions must be multiples of %d", v);
+    if (splitk > 1 && (flags & (AFR_GEMM_BIAS | AFR_GEMM_RELU | AFR_GEMM_RELU_MASK | AFR_GEMM_OUT_BF16)))
+        return fail(AFR_EINVAL, "split-K output is plain f32 partial slabs");
+    GemmParams g;
+    g.A = A; g.B = B; g.C = C; g.bias = bias; g.aux = aux; g.M = M; g.N = N; g.K = K;
+    g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldaux = ldaux; g.flags = flags; g.splitk = splitk;
+    g.slab_stride = (long long)M * ldc;
+    HIPCHK(afr_launch_gemm(dtype, g, (hipStream_t)stream));
+    return AFR_OK;
+}
+extern "C" int afr_op_reduce(float* dst, const float* slabs, int nslabs, int64_t stride, int64_t n, float scale, int acc,
+                             void* stream) {
+    if (!dst || !slabs || nslabs < 1) return fail(AFR_EINVAL, "bad reduce arguments");
+    HIPCHK(afr_launch_reduce(dst, slabs, nslabs, stride, n, scale, acc, (hipStream_t)stream));
+    return AFR_OK;
+}
+extern "C" int afr_op_adamw(float* p, const float* g, float* m, float* v, void* shadow, int64_t n, float lr, float b1,
+                            float b2, float eps, float wd, int64_t t, float gscale, void* stream) {
+    if (!p || !g || !m || !v || t < 1) return fail(AFR_EINVAL, "bad AdamW arguments");
+    const float bc1 = (float)(1.0 - std::pow((double)b1, (double)t));
+    const float bc2 = (float)(1.0 - std::pow((double)b2, (double)t));
+    HIPCHK(afr_launch_adamw(p, g, m, v, (bf16_t*)shadow, n, lr, b1, b2, eps, wd, bc1, bc2, gscale, (hipStream_t)stream));
+    return AFR_OK;
+}
+extern "C" int afr_op_mse_grad(int act_dtype, const void* u, const void* target, int tdtype, void* du, int64_t rows,
+                               int64_t cols, int64_t mean_elems, float* loss_accum, float* scratch, void* stream) {
+    if (!u || !target || !du || !loss_accum || !scratch) return fail(AFR_EINVAL, "null argument");
+    HIPCHK(afr_launch_mse_grad(act_dtype, u, target, tdtype, du, rows, cols, mean_elems, loss_accum, scratch,
+                               (hipStream_t)stream));
+    return AFR_OK;
+}
+extern "C" int afr_op_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream) {
+    HIPCHK(afr_launch_f32_to_bf16(src, (bf16_t*)dst, n, (hipStream_t)stream));
+    return AFR_OK;
+}

@@ -1,0 +1,117 @@
+// afr_common.h -- shared device helpers and the internal launcher interface of libafr.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+// ---------------------------------------------------------------------------------------------
+// Dropout counter hash.  Bit-for-bit twin of ai-font-renderer_amd/synth.py:dropout_keep_mask.
+// Stands in for the reference's torch bernoulli_ stream (model.py:137,144,149).
+// ---------------------------------------------------------------------------------------------
+__host__ __device__ __forceinline__ uint32_t afr_hash32(uint64_t idx, uint32_t key) {
+    uint32_t lo = (uint32_t)idx, hi = (uint32_t)(idx >> 32);
+    uint32_t h = lo * 0x9E3779B1u + (key + hi * 0x85EBCA6Bu);
+    h ^= h >> 16; h *= 0x21F0AAADu;
+    h ^= h >> 15; h *= 0x735A2D97u;
+    h ^= h >> 15;
+    return h;
+}
+// keep element idx iff the top 24 hash bits are below thr24 = keep_prob * 2^24
+__host__ __device__ __forceinline__ bool afr_keep(uint64_t idx, uint32_t key, uint32_t thr24) {
+    return (afr_hash32(idx, key) >> 8) < thr24;
+}
+
+static inline uint64_t afr_splitmix64(uint64_t x) {
+    uint64_t z = x + 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+enum { AFR_STREAM_EMBED = 1, AFR_STREAM_ATTN = 2, AFR_STREAM_FC = 3 };
+static inline uint32_t afr_dropout_key(uint64_t seed, uint64_t step, uint64_t stream, uint64_t rank) {
+    uint64_t v = seed ^ (step * 0x9E3779B97F4A7C15ull) ^ (stream * 0xC2B2AE3D27D4EB4Full) ^ (rank * 0x165667B19E3779F9ull);
+    return (uint32_t)(afr_splitmix64(v) & 0xFFFFFFFFull);
+}
+static inline uint32_t afr_keep_threshold(float keep_prob) { return (uint32_t)((double)keep_prob * 16777216.0); }
+
+// ---------------------------------------------------------------------------------------------
+// wave64 reductions
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+__device__ __forceinline__ float bf16_to_f32(bf16_t x) { return (float)x; }
+__device__ __forceinline__ bf16_t f32_to_bf16(float x) { return (bf16_t)x; }
+
+// ---------------------------------------------------------------------------------------------
+// internal launchers (implemented in the .hip files, called from afr_api.cpp)
+// ---------------------------------------------------------------------------------------------
+struct GemmParams {
+    const void* A; const void* B; void* C; const float* bias; const void* aux;
+    int M, N, K;
+    int lda, ldb, ldc, ldaux;
+    int flags;            // AFR_GEMM_* bits
+    int splitk;           // >=1
+    long long slab_stride;  // elements between split-K slabs of C
+};
+hipError_t afr_launch_gemm(int dtype, const GemmParams& p, hipStream_t s);
+const char* afr_gemm_kernel_name(int dtype, int flags);
+
+hipError_t afr_launch_reduce(float* dst, const float* slabs, int nslabs, long long slab_stride, long long n,
+                             float scale, int accumulate, hipStream_t s);
+hipError_t afr_launch_adamw(float* p, const float* g, float* m, float* v, bf16_t* shadow, long long n, float lr,
+                            float beta1, float beta2, float eps, float wd, float bc1, float bc2, float grad_scale,
+                            hipStream_t s);
+// loss: u (act dtype) [rows][cols] -> du in place or to `du`; per-block partial sums to scratch, then
+// a 1-block finisher adds sum(scratch) to *loss_accum (deterministic order).
+int afr_mse_blocks(long long rows, long long cols);
+hipError_t afr_launch_mse_grad(int act_dtype, const void* u, const void* target, int target_dtype, void* du,
+                               long long rows, long long cols, long long mean_elems, float* loss_accum,
+                               float* scratch, hipStream_t s);
+hipError_t afr_launch_f32_to_bf16(const float* src, bf16_t* dst, long long n, hipStream_t s);
+hipError_t afr_launch_clamp_out(int act_dtype, const void* u, float* y, long long n, hipStream_t s);
+// column sums of X[rows][cols] (act dtype) -> slabs[nsplit][cols] (f32); returns nsplit via out param
+int afr_colsum_splits(long long rows);
+hipError_t afr_launch_colsum(int act_dtype, const void* X, long long rows, long long cols, long long ld,
+                             float* slabs, hipStream_t s);
+// glyph embedding gather / deterministic scatter-add
+hipError_t afr_launch_glyph_embed(int act_dtype, const float* emb, const float* font_emb, const int64_t* x,
+                                  const int64_t* font, int B, int E, int vocab, int n_fonts, void* out,
+                                  uint32_t* err_flag, hipStream_t s);
+int afr_embed_bwd_blocks(int B);
+hipError_t afr_launch_glyph_embed_bwd(int act_dtype, const void* d, const int64_t* x, const int64_t* font, int B,
+                                      int E, int vocab, int n_fonts, float* slabs /*[blocks][(vocab+n_fonts)*E]*/,
+                                      hipStream_t s);
+
+// sheet front end (sheet.hip)
+struct SheetDims { int L, Lmax, E, H, F, vocab; };
+struct SheetParams {   // device pointers into the flat f32 parameter buffer
+    const float *pos, *emb, *w_in, *b_in, *w_o, *b_o, *ln_g, *ln_b, *w1, *b1;
+};
+struct SheetDrop { uint32_t key_e, key_a, key_f, thr_e, thr_a, thr_f; float sc_e, sc_a, sc_f; int training; };
+// offsets (in floats) of the 10 small tensors inside one partial-gradient slab == their flat-buffer offsets
+struct SheetSlabOff { int pos, emb, win, bin, wo, bo, g, b, w1, b1, total; };
+int afr_sheet_blocks(int B);
+size_t afr_sheet_fwd_lds_bytes(const SheetDims& d);
+size_t afr_sheet_bwd_lds_bytes(const SheetDims& d);
+hipError_t afr_launch_sheet_fwd(int act_dtype, const SheetDims& d, const SheetParams& P, const SheetDrop& dr,
+                                const int64_t* x, int ldx, int B, void* z, float ln_eps, uint32_t* err_flag,
+                                hipStream_t s);
+hipError_t afr_launch_sheet_bwd(int act_dtype, const SheetDims& d, const SheetParams& P, const SheetDrop& dr,
+                                const int64_t* x, int ldx, int B, const void* dz, float ln_eps, float* slabs,
+                                const SheetSlabOff& so, hipStream_t s);

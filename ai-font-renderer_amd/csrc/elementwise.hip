@@ -1,0 +1,343 @@
+// elementwise.hip -- the HBM-bound kernels of the hot path: loss/grad reduction, AdamW, slab reduction,
+// column sums (bias gradients), the glyph embedding gather and its deterministic scatter-add.
+// All are 16-byte-per-lane streaming kernels with grid-stride loops; reductions are shuffle -> LDS ->
+// per-block partial -> fixed-order finish, so every result is bitwise reproducible run to run.
+#include "afr_common.h"
+#include "../../include/afr.h"
+
+static inline int grid_for(long long work_items, int block, int max_blocks = 2048) {
+    long long g = (work_items + block - 1) / block;
+    if (g < 1) g = 1;
+    if (g > max_blocks) g = max_blocks;
+    return (int)g;
+}
+
+// ------------------------------------------------------------------------------------- reduce
+// dst[i] = (accumulate ? dst[i] : 0) + scale * sum_s slabs[s*stride + i]   (fixed s order)
+__global__ __launch_bounds__(256) void reduce_slabs_kernel(float* __restrict__ dst, const float* __restrict__ slabs,
+                                                           int nslabs, long long stride, long long n, float scale,
+                                                           int accumulate) {
+    const long long n4 = n >> 2;
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int s = 0; s < nslabs; ++s) {
+            const float4 v = *reinterpret_cast<const float4*>(slabs + s * stride + 4 * i);
+            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+        }
+        a.x *= scale; a.y *= scale; a.z *= scale; a.w *= scale;
+        float4* d = reinterpret_cast<float4*>(dst) + i;
+        if (accumulate) { float4 o = *d; a.x += o.x; a.y += o.y; a.z += o.z; a.w += o.w; }
+        *d = a;
+    }
+    // tail (n not a multiple of 4)
+    for (long long i = (n4 << 2) + blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        float a = 0.f;
+        for (int s = 0; s < nslabs; ++s) a += slabs[s * stride + i];
+        a *= scale;
+        if (accumulate) a += dst[i];
+        dst[i] = a;
+    }
+}
+hipError_t afr_launch_reduce(float* dst, const float* slabs, int nslabs, long long slab_stride, long long n,
+                             float scale, int accumulate, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(grid_for((n + 3) / 4, 256)), dim3(256), 0, s, dst, slabs, nslabs,
+                       slab_stride, n, scale, accumulate);
+    return hipGetLastError();
+}
+
+// -------------------------------------------------------------------------------------- AdamW
+// torch.optim.AdamW single-tensor update (reference model.py:273,310), one pass over p,g,m,v:
+//   p *= 1 - lr*wd;  m += (g-m)*(1-b1);  v = b2*v + (1-b2)*g*g;  p -= (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps)
+// Also refreshes the bf16 shadow copy the bf16 GEMMs read.  28 (+2) bytes per element of HBM traffic.
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                    float* __restrict__ m, float* __restrict__ v,
+                                                    bf16_t* __restrict__ shadow, long long n4, float lr, float b1,
+                                                    float b2, float eps, float wd, float step_size, float rsqrt_bc2,
+                                                    float gscale) {
+    const float decay = 1.f - lr * wd;
+    const float omb1 = 1.f - b1, omb2 = 1.f - b2;
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        float4 pp = reinterpret_cast<float4*>(p)[i];
+        float4 gg = reinterpret_cast<const float4*>(g)[i];
+        float4 mm = reinterpret_cast<float4*>(m)[i];
+        float4 vv = reinterpret_cast<float4*>(v)[i];
+        float pa[4] = {pp.x, pp.y, pp.z, pp.w}, ga[4] = {gg.x, gg.y, gg.z, gg.w};
+        float ma[4] = {mm.x, mm.y, mm.z, mm.w}, va[4] = {vv.x, vv.y, vv.z, vv.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float gk = ga[k] * gscale;
+            pa[k] *= decay;
+            ma[k] = ma[k] + (gk - ma[k]) * omb1;
+            va[k] = va[k] * b2 + omb2 * gk * gk;
+            const float denom = sqrtf(va[k]) * rsqrt_bc2 + eps;
+            pa[k] -= step_size * (ma[k] / denom);
+        }
+        reinterpret_cast<float4*>(p)[i] = make_float4(pa[0], pa[1], pa[2], pa[3]);
+        reinterpret_cast<float4*>(m)[i] = make_float4(ma[0], ma[1], ma[2], ma[3]);
+        reinterpret_cast<float4*>(v)[i] = make_float4(va[0], va[1], va[2], va[3]);
+        if (shadow) {
+            bf16x4 o = {(bf16_t)pa[0], (bf16_t)pa[1], (bf16_t)pa[2], (bf16_t)pa[3]};
+            reinterpret_cast<bf16x4*>(shadow)[i] = o;
+        }
+    }
+}
+hipError_t afr_launch_adamw(float* p, const float* g, float* m, float* v, bf16_t* shadow, long long n, float lr,
+                            float beta1, float beta2, float eps, float wd, float bc1, float bc2, float grad_scale,
+                            hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    if (n & 3) return hipErrorInvalidValue;   // flat buffers are padded to multiples of 64
+    const float step_size = lr / bc1;
+    const float rsqrt_bc2 = (float)(1.0 / sqrt((double)bc2));
+    hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n / 4, 256, 4096)), dim3(256), 0, s, p, g, m, v, shadow, n / 4, lr,
+                       beta1, beta2, eps, wd, step_size, rsqrt_bc2, grad_scale);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------- f32 -> bf16
+__global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst,
+                                                          long long n) {
+    const long long n4 = n >> 2;
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        const float4 a = reinterpret_cast<const float4*>(src)[i];
+        bf16x4 o = {(bf16_t)a.x, (bf16_t)a.y, (bf16_t)a.z, (bf16_t)a.w};
+        reinterpret_cast<bf16x4*>(dst)[i] = o;
+    }
+    for (long long i = (n4 << 2) + blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+        dst[i] = (bf16_t)src[i];
+}
+hipError_t afr_launch_f32_to_bf16(const float* src, bf16_t* dst, long long n, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(f32_to_bf16_kernel, dim3(grid_for((n + 3) / 4, 256)), dim3(256), 0, s, src, dst, n);
+    return hipGetLastError();
+}
+
+// -------------------------------------------------------------------- clamp output (eval path)
+// y = clamp(u, 0, 1) as float32: the model's output activation (reference model.py:156,202)
+template <typename T>
+__global__ __launch_bounds__(256) void clamp_out_kernel(const T* __restrict__ u, float* __restrict__ y, long long n) {
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+        y[i] = fminf(fmaxf((float)u[i], 0.f), 1.f);
+}
+hipError_t afr_launch_clamp_out(int act_dtype, const void* u, float* y, long long n, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    if (act_dtype == AFR_BF16)
+        hipLaunchKernelGGL(clamp_out_kernel<bf16_t>, dim3(grid_for(n, 256)), dim3(256), 0, s, (const bf16_t*)u, y, n);
+    else
+        hipLaunchKernelGGL(clamp_out_kernel<float>, dim3(grid_for(n, 256)), dim3(256), 0, s, (const float*)u, y, n);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------- MSE loss + gradient
+// loss = sum((clamp(u,0,1) - t)^2) / mean_elems ;  du = 2 (y - t) / mean_elems * [0 <= u <= 1]
+// (reference model.py:156,268-270 and the first step of loss.backward(), model.py:309).
+// 8 pixels per lane per iteration: u as 2 x 16 B (f32) or 16 B (bf16), target as 8 B (u8) or 2 x 16 B (f32).
+// du may alias u.  Per-lane sums -> wave shuffle -> LDS -> one partial per block -> fixed-order finisher.
+template <typename T, typename TT>
+__global__ __launch_bounds__(256) void mse_grad_kernel(const T* __restrict__ u, const TT* __restrict__ tgt,
+                                                       T* __restrict__ du, long long n8, float inv_n,
+                                                       float* __restrict__ partial) {
+    float lsum = 0.f;
+    const float g2 = 2.f * inv_n;
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n8; i += (long long)gridDim.x * 256) {
+        float uu[8], tt[8];
+        if (sizeof(T) == 4) {
+            const float4 a = reinterpret_cast<const float4*>(u)[2 * i], b = reinterpret_cast<const float4*>(u)[2 * i + 1];
+            uu[0] = a.x; uu[1] = a.y; uu[2] = a.z; uu[3] = a.w; uu[4] = b.x; uu[5] = b.y; uu[6] = b.z; uu[7] = b.w;
+        } else {
+            const bf16x8 a = reinterpret_cast<const bf16x8*>(u)[i];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) uu[k] = (float)a[k];
+        }
+        if (sizeof(TT) == 1) {
+            const uint2 a = reinterpret_cast<const uint2*>(tgt)[i];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                tt[k] = (float)((a.x >> (8 * k)) & 0xFF) / 255.0f;       // helpers.py:121: uint8 / 255.0 in float32
+                tt[4 + k] = (float)((a.y >> (8 * k)) & 0xFF) / 255.0f;
+            }
+        } else {
+            const float4 a = reinterpret_cast<const float4*>(tgt)[2 * i], b = reinterpret_cast<const float4*>(tgt)[2 * i + 1];
+            tt[0] = a.x; tt[1] = a.y; tt[2] = a.z; tt[3] = a.w; tt[4] = b.x; tt[5] = b.y; tt[6] = b.z; tt[7] = b.w;
+        }
+        float dd[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float y = fminf(fmaxf(uu[k], 0.f), 1.f);
+            const float diff = y - tt[k];
+            lsum += diff * diff;
+            dd[k] = (uu[k] >= 0.f && uu[k] <= 1.f) ? g2 * diff : 0.f;
+        }
+        if (sizeof(T) == 4) {
+            reinterpret_cast<float4*>(du)[2 * i] = make_float4(dd[0], dd[1], dd[2], dd[3]);
+            reinterpret_cast<float4*>(du)[2 * i + 1] = make_float4(dd[4], dd[5], dd[6], dd[7]);
+        } else {
+            bf16x8 o;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) o[k] = (bf16_t)dd[k];
+            reinterpret_cast<bf16x8*>(du)[i] = o;
+        }
+    }
+    __shared__ float wsum[4];
+    lsum = wave_sum(lsum);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = lsum;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+}
+__global__ __launch_bounds__(256) void loss_finish_kernel(const float* __restrict__ partial, int nblocks, float inv_n,
+                                                          float* __restrict__ loss_accum) {
+    __shared__ float sh[256];
+    float a = 0.f;
+    for (int i = threadIdx.x; i < nblocks; i += 256) a += partial[i];
+    sh[threadIdx.x] = a;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) loss_accum[0] += sh[0] * inv_n;
+}
+int afr_mse_blocks(long long rows, long long cols) { return grid_for(rows * cols / 8, 256, 1024); }
+hipError_t afr_launch_mse_grad(int act_dtype, const void* u, const void* target, int target_dtype, void* du,
+                               long long rows, long long cols, long long mean_elems, float* loss_accum,
+                               float* scratch, hipStream_t s) {
+    const long long n = rows * cols;
+    if (n <= 0) return hipSuccess;
+    if (n & 7) return hipErrorInvalidValue;
+    const int blocks = afr_mse_blocks(rows, cols);
+    const float inv_n = (float)(1.0 / (double)mean_elems);
+    dim3 g(blocks), b(256);
+#define MSE(T, TT) hipLaunchKernelGGL((mse_grad_kernel<T, TT>), g, b, 0, s, (const T*)u, (const TT*)target, (T*)du, n / 8, inv_n, scratch)
+    if (act_dtype == AFR_BF16) {
+        if (target_dtype == AFR_TARGET_U8) MSE(bf16_t, uint8_t); else MSE(bf16_t, float);
+    } else {
+        if (target_dtype == AFR_TARGET_U8) MSE(float, uint8_t); else MSE(float, float);
+    }
+#undef MSE
+    hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(256), 0, s, scratch, blocks, inv_n, loss_accum);
+    return hipGetLastError();
+}
+
+// -------------------------------------------------------------------------------- column sums
+// slabs[sp][c] = sum over the sp-th slice of rows of X[r][c]: the bias gradients db = sum_b dy (model.py:309).
+// Lane owns 4 consecutive columns (16 B f32 / 8 B bf16), rows split over blockIdx.y.
+constexpr int COLSUM_ROWS = 128;
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ X, long long rows, long long cols, long long ld,
+                                                     float* __restrict__ slabs) {
+    const long long c = (blockIdx.x * 256ll + threadIdx.x) * 4;
+    if (c >= cols) return;
+    const long long r0 = (long long)blockIdx.y * COLSUM_ROWS;
+    const long long r1 = min(rows, r0 + COLSUM_ROWS);
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    for (long long r = r0; r < r1; ++r) {
+        if (sizeof(T) == 4) {
+            const float4 v = *reinterpret_cast<const float4*>(X + r * ld + c);
+            a0 += v.x; a1 += v.y; a2 += v.z; a3 += v.w;
+        } else {
+            const bf16x4 v = *reinterpret_cast<const bf16x4*>(X + r * ld + c);
+            a0 += (float)v[0]; a1 += (float)v[1]; a2 += (float)v[2]; a3 += (float)v[3];
+        }
+    }
+    *reinterpret_cast<float4*>(slabs + (long long)blockIdx.y * cols + c) = make_float4(a0, a1, a2, a3);
+}
+int afr_colsum_splits(long long rows) { return (int)((rows + COLSUM_ROWS - 1) / COLSUM_ROWS); }
+hipError_t afr_launch_colsum(int act_dtype, const void* X, long long rows, long long cols, long long ld, float* slabs,
+                             hipStream_t s) {
+    if (rows <= 0 || cols <= 0) return hipSuccess;
+    if (cols & 3) return hipErrorInvalidValue;
+    dim3 g((unsigned)((cols / 4 + 255) / 256), (unsigned)afr_colsum_splits(rows)), b(256);
+    if (act_dtype == AFR_BF16) hipLaunchKernelGGL(colsum_kernel<bf16_t>, g, b, 0, s, (const bf16_t*)X, rows, cols, ld, slabs);
+    else hipLaunchKernelGGL(colsum_kernel<float>, g, b, 0, s, (const float*)X, rows, cols, ld, slabs);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------- glyph embedding
+// out[b][:] = Emb[x[b]][:] (+ Font[font[b]][:])  -- nn.Embedding gather (reference model.py:136,167): bit-exact row
+// copy in f32 mode.  An index outside [0,vocab) sets bit 0 of *err_flag (the reference raises IndexError) and is
+// clamped so the kernel never reads out of bounds.
+template <typename T>
+__global__ __launch_bounds__(256) void glyph_embed_kernel(const float* __restrict__ emb, const float* __restrict__ femb,
+                                                          const int64_t* __restrict__ x, const int64_t* __restrict__ font,
+                                                          int B, int E, int vocab, int n_fonts, T* __restrict__ out,
+                                                          uint32_t* err_flag) {
+    const long long total = (long long)B * E;
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int b = (int)(i / E), c = (int)(i % E);
+        long long xi = x[b];
+        if (xi < 0 || xi >= vocab) { if (c == 0) atomicOr(err_flag, 1u); xi = min(max(xi, 0ll), (long long)vocab - 1); }
+        float v = emb[xi * E + c];
+        if (n_fonts > 0) {
+            long long fi = font ? font[b] : 0;
+            if (fi < 0 || fi >= n_fonts) { if (c == 0) atomicOr(err_flag, 1u); fi = min(max(fi, 0ll), (long long)n_fonts - 1); }
+            v += femb[fi * E + c];
+        }
+        out[i] = (T)v;
+    }
+}
+hipError_t afr_launch_glyph_embed(int act_dtype, const float* emb, const float* font_emb, const int64_t* x,
+                                  const int64_t* font, int B, int E, int vocab, int n_fonts, void* out,
+                                  uint32_t* err_flag, hipStream_t s) {
+    if (B <= 0) return hipSuccess;
+    dim3 g(grid_for((long long)B * E, 256)), b(256);
+    if (act_dtype == AFR_BF16)
+        hipLaunchKernelGGL(glyph_embed_kernel<bf16_t>, g, b, 0, s, emb, font_emb, x, font, B, E, vocab, n_fonts, (bf16_t*)out, err_flag);
+    else
+        hipLaunchKernelGGL(glyph_embed_kernel<float>, g, b, 0, s, emb, font_emb, x, font, B, E, vocab, n_fonts, (float*)out, err_flag);
+    return hipGetLastError();
+}
+
+// embedding_dense_backward (model.py:309): dEmb[x[b]] += d[b].  Deterministic, atomic-free: a block takes 256 glyph
+// rows; thread (slot = tid>>5, c = tid&31) is the ONLY writer of LDS rows v with v%8 == slot, column c, and walks the
+// block's rows in order.  Block partials go to slabs[block][(vocab+n_fonts)*E]; afr_launch_reduce sums them in order.
+constexpr int EMB_BWD_ROWS = 256;
+template <typename T>
+__global__ __launch_bounds__(256) void glyph_embed_bwd_kernel(const T* __restrict__ d, const int64_t* __restrict__ x,
+                                                              const int64_t* __restrict__ font, int B, int E, int vocab,
+                                                              int n_fonts, float* __restrict__ slabs) {
+    extern __shared__ float sm[];                  // acc [(vocab+n_fonts)][E] | tile [256][E+1] | ids [256] | fids [256]
+    const int rows_tot = vocab + n_fonts;
+    const int LDT = E + 1;
+    float* acc = sm;
+    float* tile = sm + (size_t)rows_tot * E;
+    int* ids = reinterpret_cast<int*>(tile + (size_t)EMB_BWD_ROWS * LDT);
+    int* fids = ids + EMB_BWD_ROWS;
+    const int b0 = blockIdx.x * EMB_BWD_ROWS;
+    const int nb = min(EMB_BWD_ROWS, B - b0);
+    for (int i = threadIdx.x; i < rows_tot * E; i += 256) acc[i] = 0.f;
+    for (int i = threadIdx.x; i < nb * E; i += 256) tile[(i / E) * LDT + (i % E)] = (float)d[(size_t)b0 * E + i];
+    if ((int)threadIdx.x < nb) {
+        long long xi = x[b0 + threadIdx.x];
+        ids[threadIdx.x] = (int)min(max(xi, 0ll), (long long)vocab - 1);
+        long long fi = (n_fonts > 0 && font) ? font[b0 + threadIdx.x] : 0;
+        fids[threadIdx.x] = (int)min(max(fi, 0ll), (long long)max(n_fonts, 1) - 1);
+    }
+    __syncthreads();
+    const int slot = threadIdx.x >> 5, c0 = threadIdx.x & 31;
+    for (int c = c0; c < E; c += 32) {
+        for (int r = 0; r < nb; ++r) {
+            const int v = ids[r];
+            const float val = tile[r * LDT + c];
+            if ((v & 7) == slot) acc[v * E + c] += val;
+            if (n_fonts > 0) {
+                const int f = fids[r];
+                if ((f & 7) == slot) acc[(vocab + f) * E + c] += val;
+            }
+        }
+    }
+    __syncthreads();
+    float* out = slabs + (size_t)blockIdx.x * rows_tot * E;
+    for (int i = threadIdx.x; i < rows_tot * E; i += 256) out[i] = acc[i];
+}
+int afr_embed_bwd_blocks(int B) { return (B + EMB_BWD_ROWS - 1) / EMB_BWD_ROWS; }
+hipError_t afr_launch_glyph_embed_bwd(int act_dtype, const void* d, const int64_t* x, const int64_t* font, int B, int E,
+                                      int vocab, int n_fonts, float* slabs, hipStream_t s) {
+    if (B <= 0) return hipSuccess;
+    const size_t lds = ((size_t)(vocab + n_fonts) * E + (size_t)EMB_BWD_ROWS * (E + 1)) * sizeof(float) + 2 * EMB_BWD_ROWS * sizeof(int);
+    dim3 g(afr_embed_bwd_blocks(B)), b(256);
+    if (act_dtype == AFR_BF16)
+        hipLaunchKernelGGL(glyph_embed_bwd_kernel<bf16_t>, g, b, lds, s, (const bf16_t*)d, x, font, B, E, vocab, n_fonts, slabs);
+    else
+        hipLaunchKernelGGL(glyph_embed_bwd_kernel<float>, g, b, lds, s, (const float*)d, x, font, B, E, vocab, n_fonts, slabs);
+    return hipGetLastError();
+}

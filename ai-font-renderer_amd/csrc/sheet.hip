@@ -1,0 +1,460 @@
+// sheet.hip -- the sheet model's per-string front end, fused into one kernel per direction.
+//
+// Forward (reference model.py:167-193): embedding gather -> dropout -> + learned positions -> packed in-proj ->
+// 4-head 100x100 softmax attention (dropout on the probabilities) -> out-proj -> residual + LayerNorm ->
+// fc1 + ReLU + dropout -> flattened (zero-padded) feature row z[b][max_length*64], the A operand of fc_output.
+// Backward (model.py:309) recomputes that chain in LDS from the same counter-hash dropout stream instead of
+// saving activations (a sample's whole state is <100 KB of LDS), then walks it in reverse.
+//
+// One 256-thread workgroup owns one string at a time and loops over strings (persistent grid, <= 256 blocks):
+// weights are loaded into LDS once.  Every reduction has a single owner thread and a fixed order -- no atomics:
+//   * attention backward is split by ROW (softmax statistics, delta, dq) and then by COLUMN (dk, dv), each
+//     recomputing the scores it needs, so dv/dk need no scatter;
+//   * the 10 small parameter gradients accumulate across the block's strings in registers (dEmb in LDS, row v
+//     owned by thread slot v%8) and leave as one partial slab per block, summed in block order by reduce_slabs.
+// E=32, 4 heads of 8, fc1 width 64 are compile-time (the reference hard-codes them: model.py:79,81,148).
+#include "afr_common.h"
+#include "../../include/afr.h"
+
+namespace {
+constexpr int E = 32, H = 4, D = 8, F = 64, QKV = 96;
+constexpr int SE = 33, SQ = 97;                 // padded LDS row strides
+constexpr int W_FLOATS = QKV * SE + QKV + E * SE + E + E + E + F * SE + F;   // weights block
+
+struct Wts { float *Win, *bin, *Wo, *bo, *lg, *lb, *W1, *b1; };
+
+__device__ __forceinline__ Wts carve_weights(float* sm) {
+    Wts w;
+    w.Win = sm; w.bin = w.Win + QKV * SE; w.Wo = w.bin + QKV; w.bo = w.Wo + E * SE;
+    w.lg = w.bo + E; w.lb = w.lg + E; w.W1 = w.lb + E; w.b1 = w.W1 + F * SE;
+    return w;
+}
+__device__ __forceinline__ void load_weights(const Wts& w, const SheetParams& P, int tid) {
+    for (int i = tid; i < QKV * E; i += 256) w.Win[(i >> 5) * SE + (i & 31)] = P.w_in[i];
+    for (int i = tid; i < E * E; i += 256) w.Wo[(i >> 5) * SE + (i & 31)] = P.w_o[i];
+    for (int i = tid; i < F * E; i += 256) w.W1[(i >> 5) * SE + (i & 31)] = P.w1[i];
+    if (tid < QKV) w.bin[tid] = P.b_in[tid];
+    if (tid < E) { w.bo[tid] = P.b_o[tid]; w.lg[tid] = P.ln_g[tid]; w.lb[tid] = P.ln_b[tid]; }
+    if (tid < F) w.b1[tid] = P.b1[tid];
+}
+
+// ---- shared forward pieces (used by both kernels so that backward's recomputation is bit-identical) ----------
+__device__ __forceinline__ void ph_tokens(int* tok, const int64_t* x, int ldx, int b, int L, int vocab, uint32_t* err, int tid) {
+    if (tid < L) {
+        long long v = x[(size_t)b * ldx + tid];
+        if (v < 0 || v >= vocab) { if (err) atomicOr(err, 1u); v = v < 0 ? 0 : vocab - 1; }
+        tok[tid] = (int)v;
+    }
+}
+// e = dropout(Emb[x]) + P[:L]                                                  (model.py:167-172)
+__device__ __forceinline__ void ph_embed(float* e, const int* tok, const SheetParams& P, const SheetDrop& dr, int b, int L, int tid) {
+    for (int i = tid; i < L * E; i += 256) {
+        const int l = i >> 5, c = i & 31;
+        float v = P.emb[tok[l] * E + c];
+        if (dr.training) v = afr_keep((uint64_t)b * L * E + i, dr.key_e, dr.thr_e) ? v * dr.sc_e : 0.f;
+        e[l * SE + c] = v + P.pos[i];
+    }
+}
+// qkv = e . W_in^T + b_in                                                       (packed in-proj of nn.MultiheadAttention)
+__device__ __forceinline__ void ph_inproj(float* qkv, const float* e, const Wts& w, int L, int tid) {
+    for (int i = tid; i < L * QKV; i += 256) {
+        const int l = i / QKV, j = i - l * QKV;
+        float a = w.bin[j];
+#pragma unroll
+        for (int c = 0; c < E; ++c) a = fmaf(e[l * SE + c], w.Win[j * SE + c], a);
+        qkv[l * SQ + j] = a;
+    }
+}
+__device__ __forceinline__ float attn_mask(const SheetDrop& dr, int b, int h, int i, int j, int L) {
+    if (!dr.training) return 1.f;
+    const uint64_t idx = (((uint64_t)b * H + h) * L + i) * L + j;
+    return afr_keep(idx, dr.key_a, dr.thr_a) ? dr.sc_a : 0.f;
+}
+// o = concat_h( dropout(softmax((q/sqrt(D)) k^T)) v )      one thread per (head, query row)
+__device__ __forceinline__ void ph_attention(float* o, const float* qkv, const SheetDrop& dr, int b, int L, int tid) {
+    const float scale = 0.35355339059327373f;    // sqrt(1/8), applied to q as torch does
+    for (int r = tid; r < H * L; r += 256) {
+        const int h = r / L, i = r - h * L;
+        float q[D];
+#pragma unroll
+        for (int d = 0; d < D; ++d) q[d] = qkv[i * SQ + h * D + d] * scale;
+        float mx = -INFINITY;
+        for (int j = 0; j < L; ++j) {
+            float s = 0.f;
+#pragma unroll
+            for (int d = 0; d < D; ++d) s = fmaf(q[d], qkv[j * SQ + E + h * D + d], s);
+            mx = fmaxf(mx, s);
+        }
+        float sum = 0.f, acc[D];
+#pragma unroll
+        for (int d = 0; d < D; ++d) acc[d] = 0.f;
+        for (int j = 0; j < L; ++j) {
+            float s = 0.f;
+#pragma unroll
+            for (int d = 0; d < D; ++d) s = fmaf(q[d], qkv[j * SQ + E + h * D + d], s);
+            const float p = expf(s - mx);
+            sum += p;
+            const float pm = p * attn_mask(dr, b, h, i, j, L);
+#pragma unroll
+            for (int d = 0; d < D; ++d) acc[d] = fmaf(pm, qkv[j * SQ + 2 * E + h * D + d], acc[d]);
+        }
+        const float inv = 1.f / sum;
+#pragma unroll
+        for (int d = 0; d < D; ++d) o[i * SE + h * D + d] = acc[d] * inv;
+    }
+}
+// r = e + o . W_o^T + b_o                                                       (model.py:176-180)
+__device__ __forceinline__ void ph_outproj_res(float* r, const float* e, const float* o, const Wts& w, int L, int tid) {
+    for (int i = tid; i < L * E; i += 256) {
+        const int l = i >> 5, c = i & 31;
+        float a = w.bo[c];
+#pragma unroll
+        for (int k = 0; k < E; ++k) a = fmaf(o[l * SE + k], w.Wo[c * SE + k], a);
+        r[l * SE + c] = e[l * SE + c] + a;
+    }
+}
+// LayerNorm over the 32 channels, biased variance: xh <- (r-mu)*rstd in place, n <- xh*gamma+beta, rstd kept
+__device__ __forceinline__ void ph_layernorm(float* xh, float* n, float* rstd, const Wts& w, int L, float eps, int tid) {
+    if (tid < L) {
+        float* row = xh + tid * SE;
+        float mu = 0.f;
+#pragma unroll
+        for (int c = 0; c < E; ++c) mu += row[c];
+        mu *= (1.f / E);
+        float var = 0.f;
+#pragma unroll
+        for (int c = 0; c < E; ++c) { const float dlt = row[c] - mu; var = fmaf(dlt, dlt, var); }
+        var *= (1.f / E);
+        const float rs = 1.f / sqrtf(var + eps);
+        rstd[tid] = rs;
+#pragma unroll
+        for (int c = 0; c < E; ++c) {
+            const float xv = (row[c] - mu) * rs;
+            row[c] = xv;
+            n[tid * SE + c] = fmaf(xv, w.lg[c], w.lb[c]);
+        }
+    }
+}
+__device__ __forceinline__ float fc_mask(const SheetDrop& dr, int b, int L, int i) {
+    if (!dr.training) return 1.f;
+    return afr_keep((uint64_t)b * L * F + i, dr.key_f, dr.thr_f) ? dr.sc_f : 0.f;
+}
+__device__ __forceinline__ float fc1_pre(const float* n, const Wts& w, int l, int j) {
+    float a = w.b1[j];
+#pragma unroll
+    for (int c = 0; c < E; ++c) a = fmaf(n[l * SE + c], w.W1[j * SE + c], a);
+    return a;
+}
+
+// ------------------------------------------------------------------------------------------ forward kernel
+template <typename T>
+__global__ __launch_bounds__(256) void sheet_fwd_kernel(SheetDims dm, SheetParams P, SheetDrop dr, const int64_t* __restrict__ x,
+                                                        int ldx, int B, T* __restrict__ z, float eps, uint32_t* err) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int tid = threadIdx.x, L = dm.L;
+    const Wts w = carve_weights(sm);
+    float* e = sm + W_FLOATS;
+    float* qkv = e + L * SE;
+    float* o = qkv + L * SQ;
+    float* r = o + L * SE;
+    float* n = r + L * SE;
+    float* rstd = n + L * SE;
+    int* tok = reinterpret_cast<int*>(rstd + L);
+    load_weights(w, P, tid);
+    const size_t Kz = (size_t)dm.Lmax * F;
+    for (int b = blockIdx.x; b < B; b += gridDim.x) {
+        ph_tokens(tok, x, ldx, b, L, dm.vocab, err, tid);
+        __syncthreads();
+        ph_embed(e, tok, P, dr, b, L, tid);
+        __syncthreads();
+        ph_inproj(qkv, e, w, L, tid);
+        __syncthreads();
+        ph_attention(o, qkv, dr, b, L, tid);
+        __syncthreads();
+        ph_outproj_res(r, e, o, w, L, tid);
+        __syncthreads();
+        ph_layernorm(r, n, rstd, w, L, eps, tid);
+        __syncthreads();
+        T* zr = z + (size_t)b * Kz;
+        for (int i = tid; i < L * F; i += 256) {                    // fc1 + ReLU + dropout, model.py:183-184
+            const int l = i >> 6, j = i & 63;
+            const float f = fmaxf(fc1_pre(n, w, l, j), 0.f);
+            zr[i] = (T)(f * fc_mask(dr, b, L, i));
+        }
+        for (size_t i = (size_t)L * F + tid; i < Kz; i += 256) zr[i] = (T)0.f;   // zero-pad branch, model.py:190-193
+        __syncthreads();
+    }
+}
+
+// ----------------------------------------------------------------------------------------- backward kernel
+__device__ __forceinline__ float dqkv_at(const float* dq, const float* big, int l, int j) {
+    return j < E ? dq[l * SE + j] : big[l * SQ + j];
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void sheet_bwd_kernel(SheetDims dm, SheetParams P, SheetDrop dr, const int64_t* __restrict__ x,
+                                                        int ldx, int B, const T* __restrict__ dz, float eps,
+                                                        float* __restrict__ slabs, SheetSlabOff so) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int tid = threadIdx.x, L = dm.L;
+    const Wts w = carve_weights(sm);
+    float* e = sm + W_FLOATS;          // [L][33]   whole sample
+    float* big = e + L * SE;           // [L][97]   qkv  | later n [L][33] + df [L][64] | later qkv again -> dk,dv in place
+    float* o = big + L * SQ;           // [L][33]   o    | later dq
+    float* xh = o + L * SE;            // [L][33]   r -> xhat | later dO (grad wrt attention output o)
+    float* dn = xh + L * SE;           // [L][33]   dn -> dr -> de
+    float* rstd = dn + L * SE;         // [L]
+    float* smax = rstd + L;            // [4L]
+    float* sinv = smax + H * L;        // [4L]
+    float* sdel = sinv + H * L;        // [4L]
+    float* demb = sdel + H * L;        // [vocab][32]
+    int* tok = reinterpret_cast<int*>(demb + dm.vocab * E);
+    float* nbuf = big;                 // n  [L][33]
+    float* df = big + L * SE;          // df [L][64]
+    load_weights(w, P, tid);
+    for (int i = tid; i < dm.vocab * E; i += 256) demb[i] = 0.f;
+
+    const int c32 = tid & 31, g8 = tid >> 5;
+    float aW1[8], aWo[4], aWin[12], aPos[15];
+    float a_b1 = 0.f, a_bo = 0.f, a_g = 0.f, a_b = 0.f, a_bin = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) aW1[k] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) aWo[k] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 12; ++k) aWin[k] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 15; ++k) aPos[k] = 0.f;
+    const float scale = 0.35355339059327373f;
+    const size_t Kz = (size_t)dm.Lmax * F;
+
+    for (int b = blockIdx.x; b < B; b += gridDim.x) {
+        // ---- recompute the forward chain
+        ph_tokens(tok, x, ldx, b, L, dm.vocab, nullptr, tid);
+        __syncthreads();
+        ph_embed(e, tok, P, dr, b, L, tid);
+        __syncthreads();
+        ph_inproj(big, e, w, L, tid);
+        __syncthreads();
+        ph_attention(o, big, dr, b, L, tid);
+        __syncthreads();
+        ph_outproj_res(xh, e, o, w, L, tid);
+        __syncthreads();
+        ph_layernorm(xh, nbuf, rstd, w, L, eps, tid);        // qkv dead: n overwrites the front of `big`
+        __syncthreads();
+        // ---- df = dz * dropout-mask * [pre>0]
+        const T* dzr = dz + (size_t)b * Kz;
+        for (int i = tid; i < L * F; i += 256) {
+            const int l = i >> 6, j = i & 63;
+            const float pre = fc1_pre(nbuf, w, l, j);
+            df[i] = pre > 0.f ? (float)dzr[i] * fc_mask(dr, b, L, i) : 0.f;
+        }
+        __syncthreads();
+        // ---- dW1 += df^T n ; db1 += sum df ; dn = df . W1
+        for (int l = 0; l < L; ++l) {
+            const float nv = nbuf[l * SE + c32];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) aW1[k] = fmaf(df[l * F + g8 + 8 * k], nv, aW1[k]);
+        }
+        if (tid < F) { float a = 0.f; for (int l = 0; l < L; ++l) a += df[l * F + tid]; a_b1 += a; }
+        for (int i = tid; i < L * E; i += 256) {
+            const int l = i >> 5, c = i & 31;
+            float a = 0.f;
+#pragma unroll
+            for (int j = 0; j < F; ++j) a = fmaf(df[l * F + j], w.W1[j * SE + c], a);
+            dn[l * SE + c] = a;
+        }
+        __syncthreads();
+        // ---- LayerNorm backward: dgamma, dbeta (column owners), then dr in place (row owners)
+        if (tid < E) { float a = 0.f; for (int l = 0; l < L; ++l) a = fmaf(dn[l * SE + tid], xh[l * SE + tid], a); a_g += a; }
+        else if (tid < 2 * E) { const int c = tid - E; float a = 0.f; for (int l = 0; l < L; ++l) a += dn[l * SE + c]; a_b += a; }
+        __syncthreads();
+        if (tid < L) {
+            float* row = dn + tid * SE;
+            const float* xr = xh + tid * SE;
+            float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+            for (int c = 0; c < E; ++c) { const float gv = row[c] * w.lg[c]; m1 += gv; m2 = fmaf(gv, xr[c], m2); }
+            m1 *= (1.f / E); m2 *= (1.f / E);
+            const float rs = rstd[tid];
+#pragma unroll
+            for (int c = 0; c < E; ++c) row[c] = (row[c] * w.lg[c] - m1 - xr[c] * m2) * rs;
+        }
+        __syncthreads();
+        // ---- out-proj backward: dWo += dr^T o ; dbo += sum dr ; dO = dr . Wo  (written over xhat, which is dead)
+        for (int l = 0; l < L; ++l) {
+            const float ov = o[l * SE + c32];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) aWo[k] = fmaf(dn[l * SE + g8 + 8 * k], ov, aWo[k]);
+        }
+        if (tid < E) { float a = 0.f; for (int l = 0; l < L; ++l) a += dn[l * SE + tid]; a_bo += a; }
+        __syncthreads();                                     // all reads of xhat (LN backward) are done
+        for (int i = tid; i < L * E; i += 256) {
+            const int l = i >> 5, c = i & 31;
+            float a = 0.f;
+#pragma unroll
+            for (int k = 0; k < E; ++k) a = fmaf(dn[l * SE + k], w.Wo[k * SE + c], a);
+            xh[l * SE + c] = a;
+        }
+        __syncthreads();                                     // n, df dead; o dead after the dWo loop above
+        ph_inproj(big, e, w, L, tid);                        // recompute qkv
+        __syncthreads();
+        // ---- attention backward, by ROW: softmax stats, delta = sum_j dA.A, dq      (dq -> `o` buffer)
+        for (int r = tid; r < H * L; r += 256) {
+            const int h = r / L, i = r - h * L;
+            float q[D], dO[D];
+#pragma unroll
+            for (int d = 0; d < D; ++d) { q[d] = big[i * SQ + h * D + d] * scale; dO[d] = xh[i * SE + h * D + d]; }
+            float mx = -INFINITY;
+            for (int j = 0; j < L; ++j) {
+                float s = 0.f;
+#pragma unroll
+                for (int d = 0; d < D; ++d) s = fmaf(q[d], big[j * SQ + E + h * D + d], s);
+                mx = fmaxf(mx, s);
+            }
+            float sum = 0.f, num = 0.f;
+            for (int j = 0; j < L; ++j) {
+                float s = 0.f, dA = 0.f;
+#pragma unroll
+                for (int d = 0; d < D; ++d) {
+                    s = fmaf(q[d], big[j * SQ + E + h * D + d], s);
+                    dA = fmaf(dO[d], big[j * SQ + 2 * E + h * D + d], dA);
+                }
+                const float p = expf(s - mx);
+                sum += p;
+                num = fmaf(p, dA * attn_mask(dr, b, h, i, j, L), num);
+            }
+            const float inv = 1.f / sum, delta = num * inv;
+            smax[r] = mx; sinv[r] = inv; sdel[r] = delta;
+            float dq[D];
+#pragma unroll
+            for (int d = 0; d < D; ++d) dq[d] = 0.f;
+            for (int j = 0; j < L; ++j) {
+                float s = 0.f, dA = 0.f;
+#pragma unroll
+                for (int d = 0; d < D; ++d) {
+                    s = fmaf(q[d], big[j * SQ + E + h * D + d], s);
+                    dA = fmaf(dO[d], big[j * SQ + 2 * E + h * D + d], dA);
+                }
+                const float p = expf(s - mx) * inv;
+                const float dS = p * (dA * attn_mask(dr, b, h, i, j, L) - delta);
+#pragma unroll
+                for (int d = 0; d < D; ++d) dq[d] = fmaf(dS, big[j * SQ + E + h * D + d], dq[d]);
+            }
+#pragma unroll
+            for (int d = 0; d < D; ++d) o[i * SE + h * D + d] = dq[d] * scale;
+        }
+        __syncthreads();
+        // ---- attention backward, by COLUMN: dk_j, dv_j (written over k_j, v_j, which only this thread reads)
+        for (int r = tid; r < H * L; r += 256) {
+            const int h = r / L, j = r - h * L;
+            float kk[D], vv[D], dk[D], dv[D];
+#pragma unroll
+            for (int d = 0; d < D; ++d) { kk[d] = big[j * SQ + E + h * D + d]; vv[d] = big[j * SQ + 2 * E + h * D + d]; dk[d] = 0.f; dv[d] = 0.f; }
+            for (int i = 0; i < L; ++i) {
+                float s = 0.f, dA = 0.f, qs[D], dO[D];
+#pragma unroll
+                for (int d = 0; d < D; ++d) {
+                    qs[d] = big[i * SQ + h * D + d] * scale;
+                    dO[d] = xh[i * SE + h * D + d];
+                    s = fmaf(qs[d], kk[d], s);
+                    dA = fmaf(dO[d], vv[d], dA);
+                }
+                const float p = expf(s - smax[h * L + i]) * sinv[h * L + i];
+                const float m = attn_mask(dr, b, h, i, j, L);
+                const float dS = p * (dA * m - sdel[h * L + i]);
+                const float pm = p * m;
+#pragma unroll
+                for (int d = 0; d < D; ++d) { dk[d] = fmaf(dS, qs[d], dk[d]); dv[d] = fmaf(pm, dO[d], dv[d]); }
+            }
+#pragma unroll
+            for (int d = 0; d < D; ++d) { big[j * SQ + E + h * D + d] = dk[d]; big[j * SQ + 2 * E + h * D + d] = dv[d]; }
+        }
+        __syncthreads();
+        // ---- in-proj backward: dWin += dqkv^T e ; dbin += sum dqkv ; de = dr + dqkv . Win   (de in place over dr)
+        for (int l = 0; l < L; ++l) {
+            const float ev = e[l * SE + c32];
+#pragma unroll
+            for (int k = 0; k < 12; ++k) aWin[k] = fmaf(dqkv_at(o, big, l, g8 + 8 * k), ev, aWin[k]);
+        }
+        if (tid < QKV) { float a = 0.f; for (int l = 0; l < L; ++l) a += dqkv_at(o, big, l, tid); a_bin += a; }
+        for (int i = tid; i < L * E; i += 256) {
+            const int l = i >> 5, c = i & 31;
+            float a = dn[l * SE + c];
+#pragma unroll 8
+            for (int j = 0; j < QKV; ++j) a = fmaf(dqkv_at(o, big, l, j), w.Win[j * SE + c], a);
+            dn[l * SE + c] = a;
+        }
+        __syncthreads();
+        // ---- dP += de ; dEmb[tok] += de * embed-dropout-mask       (row v of dEmb owned by thread slot v%8)
+#pragma unroll
+        for (int k = 0; k < 15; ++k) { const int l = g8 + 8 * k; if (l < L) aPos[k] += dn[l * SE + c32]; }
+        for (int l = 0; l < L; ++l) {
+            const int v = tok[l];
+            if ((v & 7) == g8) {
+                float m = 1.f;
+                if (dr.training) m = afr_keep((uint64_t)b * L * E + l * E + c32, dr.key_e, dr.thr_e) ? dr.sc_e : 0.f;
+                demb[v * E + c32] += dn[l * SE + c32] * m;
+            }
+        }
+        __syncthreads();
+    }
+    // ---- one partial slab per block, laid out like the flat parameter buffer (pads were zeroed by the host memset)
+    float* S = slabs + (size_t)blockIdx.x * so.total;
+#pragma unroll
+    for (int k = 0; k < 15; ++k) { const int l = g8 + 8 * k; if (l < L) S[so.pos + l * E + c32] = aPos[k]; }
+    for (int i = tid; i < dm.vocab * E; i += 256) S[so.emb + i] = demb[i];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) S[so.win + (g8 + 8 * k) * E + c32] = aWin[k];
+    if (tid < QKV) S[so.bin + tid] = a_bin;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) S[so.wo + (g8 + 8 * k) * E + c32] = aWo[k];
+    if (tid < E) { S[so.bo + tid] = a_bo; S[so.g + tid] = a_g; }
+    else if (tid < 2 * E) S[so.b + tid - E] = a_b;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) S[so.w1 + (g8 + 8 * k) * E + c32] = aW1[k];
+    if (tid < F) S[so.b1 + tid] = a_b1;
+}
+}  // namespace
+
+int afr_sheet_blocks(int B) { return B < 256 ? B : 256; }
+size_t afr_sheet_fwd_lds_bytes(const SheetDims& d) {
+    return (size_t)(W_FLOATS + 4 * d.L * SE + d.L * SQ + 2 * d.L) * sizeof(float);
+}
+size_t afr_sheet_bwd_lds_bytes(const SheetDims& d) {
+    return (size_t)(W_FLOATS + 4 * d.L * SE + d.L * SQ + d.L + 3 * H * d.L + d.vocab * E + d.L) * sizeof(float);
+}
+
+hipError_t afr_launch_sheet_fwd(int act_dtype, const SheetDims& d, const SheetParams& P, const SheetDrop& dr, const int64_t* x,
+                                int ldx, int B, void* z, float ln_eps, uint32_t* err_flag, hipStream_t s) {
+    if (B <= 0) return hipSuccess;
+    const size_t lds = afr_sheet_fwd_lds_bytes(d);
+    dim3 g(afr_sheet_blocks(B)), blk(256);
+    hipError_t e;
+    if (act_dtype == AFR_BF16) {
+        if ((e = hipFuncSetAttribute((const void*)sheet_fwd_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
+        hipLaunchKernelGGL(sheet_fwd_kernel<bf16_t>, g, blk, lds, s, d, P, dr, x, ldx, B, (bf16_t*)z, ln_eps, err_flag);
+    } else {
+        if ((e = hipFuncSetAttribute((const void*)sheet_fwd_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
+        hipLaunchKernelGGL(sheet_fwd_kernel<float>, g, blk, lds, s, d, P, dr, x, ldx, B, (float*)z, ln_eps, err_flag);
+    }
+    return hipGetLastError();
+}
+
+hipError_t afr_launch_sheet_bwd(int act_dtype, const SheetDims& d, const SheetParams& P, const SheetDrop& dr, const int64_t* x,
+                                int ldx, int B, const void* dz, float ln_eps, float* slabs, const SheetSlabOff& so, hipStream_t s) {
+    if (B <= 0) return hipSuccess;
+    const size_t lds = afr_sheet_bwd_lds_bytes(d);
+    const int nb = afr_sheet_blocks(B);
+    hipError_t e = hipMemsetAsync(slabs, 0, (size_t)nb * so.total * sizeof(float), s);
+    if (e != hipSuccess) return e;
+    dim3 g(nb), blk(256);
+    if (act_dtype == AFR_BF16) {
+        if ((e = hipFuncSetAttribute((const void*)sheet_bwd_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
+        hipLaunchKernelGGL(sheet_bwd_kernel<bf16_t>, g, blk, lds, s, d, P, dr, x, ldx, B, (const bf16_t*)dz, ln_eps, slabs, so);
+    } else {
+        if ((e = hipFuncSetAttribute((const void*)sheet_bwd_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
+        hipLaunchKernelGGL(sheet_bwd_kernel<float>, g, blk, lds, s, d, P, dr, x, ldx, B, (const float*)dz, ln_eps, slabs, so);
+    }
+    return hipGetLastError();
+}

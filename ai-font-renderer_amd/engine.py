@@ -1,0 +1,213 @@
+"""Host-side driver of libafr.so: owns the device buffers (as PyTorch-ROCm tensors -- torch is only
+the allocator and the stream provider here) and mirrors one training iteration of the reference
+loop body (model.py:292-310) as forward -> loss_grad -> backward -> [all-reduce] -> adamw.
+
+Needs a GPU and the built extension; raises otherwise (no CPU path).
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from .config import GlyphConfig, SheetConfig
+
+_DT = {"f32": _lib.AFR_F32, "fp32": _lib.AFR_F32, "float32": _lib.AFR_F32, "bf16": _lib.AFR_BF16, "bfloat16": _lib.AFR_BF16}
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def make_afr_config(cfg, dtype, max_batch, seed=42, rank=0):
+    c = _lib.AfrConfig()
+    c.dtype = _DT[dtype]
+    c.max_batch = int(max_batch)
+    c.vocab = cfg.vocab
+    c.embed_dim = cfg.embed_dim
+    c.seed = int(seed)
+    c.rank = int(rank)
+    if isinstance(cfg, SheetConfig):
+        c.kind = _lib.AFR_KIND_SHEET
+        c.out_h, c.out_w = cfg.sheet_h, cfg.sheet_w
+        c.max_length, c.heads, c.fc_dim = cfg.max_length, cfg.heads, cfg.fc_dim
+        c.p_embed, c.p_attn, c.p_fc, c.ln_eps = cfg.p_embed, cfg.p_attn, cfg.p_fc, cfg.ln_eps
+    elif isinstance(cfg, GlyphConfig):
+        c.kind = _lib.AFR_KIND_GLYPH
+        c.out_h, c.out_w = cfg.out_h, cfg.out_w
+        c.n_hidden = len(cfg.hidden)
+        for i, h in enumerate(cfg.hidden):
+            c.hidden[i] = h
+        c.n_fonts = cfg.n_fonts
+    else:
+        raise TypeError(f"unknown config {type(cfg)}")
+    return c
+
+
+class Engine:
+    """One plan + its device buffers.  `params[name]` are views into the flat float32 buffer in
+    state_dict order, so checkpoints interchange with the reference (helpers.py:76-105)."""
+
+    def __init__(self, cfg, dtype="f32", max_batch=1024, device=None, seed=42, rank=0, with_optimizer=True):
+        if not torch.cuda.is_available():
+            raise RuntimeError("ai_font_renderer_amd.Engine needs an MI355X: the hot path has no CPU fallback")
+        self.lib = _lib.lib()
+        self.cfg, self.dtype, self.max_batch = cfg, dtype, int(max_batch)
+        self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+        self._c = make_afr_config(cfg, dtype, max_batch, seed, rank)
+        self._plan = C.c_void_p()
+        _lib.check(self.lib.afr_plan_create(C.byref(self._c), C.byref(self._plan)))
+        n = self.lib.afr_param_elems(self._plan)
+        self.n_flat = int(n)
+        with torch.cuda.device(self.device):
+            self.flat_params = torch.zeros(n, dtype=torch.float32, device=self.device)
+            self.flat_grads = torch.zeros(n, dtype=torch.float32, device=self.device)
+            self.exp_avg = torch.zeros(n, dtype=torch.float32, device=self.device) if with_optimizer else None
+            self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=self.device) if with_optimizer else None
+            self.ws_bytes = int(self.lib.afr_workspace_bytes(self._plan))
+            self.workspace = torch.zeros(self.ws_bytes, dtype=torch.uint8, device=self.device)
+            self.loss_accum = torch.zeros(1, dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.afr_bind(self._plan, _ptr(self.flat_params), _ptr(self.flat_grads), _ptr(self.exp_avg),
+                                     _ptr(self.exp_avg_sq), _ptr(self.workspace), self.ws_bytes))
+        self.layout = []
+        name = C.create_string_buffer(128)
+        off, numel, ndim = C.c_int64(), C.c_int64(), C.c_int32()
+        shape = (C.c_int64 * 4)()
+        for i in range(self.lib.afr_param_count(self._plan)):
+            _lib.check(self.lib.afr_param_info(self._plan, i, name, 128, C.byref(off), C.byref(numel), C.byref(ndim), shape))
+            self.layout.append((name.value.decode(), tuple(shape[k] for k in range(ndim.value)), off.value, numel.value))
+        self.params = {nm: self.flat_params[o:o + k].view(shp) for nm, shp, o, k in self.layout}
+        self.grads = {nm: self.flat_grads[o:o + k].view(shp) for nm, shp, o, k in self.layout}
+        self.pixels = cfg.pixels
+        self.t = 0            # AdamW step counter (model.py:310)
+        self._keep = None     # keeps the last inputs alive until backward has consumed them
+
+    def __del__(self):
+        try:
+            if getattr(self, "_plan", None):
+                self.lib.afr_plan_destroy(self._plan)
+                self._plan = None
+        except Exception:
+            pass
+
+    # ---------------------------------------------------------------- parameters
+    def load_params(self, tensors):
+        """tensors: dict name -> numpy array / torch tensor (any device), state_dict keys."""
+        for nm, shp, _, _ in self.layout:
+            src = tensors[nm]
+            src = torch.from_numpy(np.ascontiguousarray(src)) if isinstance(src, np.ndarray) else src.detach()
+            if tuple(src.shape) != tuple(shp):
+                raise ValueError(f"{nm}: shape {tuple(src.shape)} != {tuple(shp)}")
+            self.params[nm].copy_(src.to(torch.float32))
+        self.sync_params()
+
+    def sync_params(self):
+        _lib.check(self.lib.afr_sync_params(self._plan, _stream()))
+
+    def state_dict(self):
+        return {nm: self.params[nm].detach().clone() for nm, _, _, _ in self.layout}
+
+    def reset_optimizer(self):
+        self.exp_avg.zero_()
+        self.exp_avg_sq.zero_()
+        self.t = 0
+
+    # ---------------------------------------------------------------- the hot path
+    def _prep_x(self, x, font):
+        x = x.to(self.device, dtype=torch.int64, non_blocking=True).contiguous()
+        if font is not None:
+            font = font.to(self.device, dtype=torch.int64, non_blocking=True).contiguous()
+        return x, font
+
+    def forward(self, x, font=None, training=False, step=0, want_output=True):
+        x, font = self._prep_x(x, font)
+        if isinstance(self.cfg, SheetConfig):
+            if x.dim() != 2:
+                raise ValueError("sheet model takes int64 [B, L] codes")
+            B, L = x.shape
+        else:
+            x = x.reshape(-1)
+            B, L = x.shape[0], 1
+        y = torch.empty(B, self.pixels, dtype=torch.float32, device=self.device) if want_output else None
+        _lib.check(self.lib.afr_forward(self._plan, _ptr(x), _ptr(font), B, L, _ptr(y), int(bool(training)), int(step), _stream()))
+        self._keep = (x, font)
+        if y is None:
+            return None
+        h, w = (self.cfg.sheet_h, self.cfg.sheet_w) if isinstance(self.cfg, SheetConfig) else (self.cfg.out_h, self.cfg.out_w)
+        return y.view(B, h, w)
+
+    def _target(self, target):
+        if target.dtype == torch.uint8:
+            return target.to(self.device, non_blocking=True).contiguous(), _lib.AFR_TARGET_U8
+        return target.to(self.device, dtype=torch.float32, non_blocking=True).contiguous(), _lib.AFR_TARGET_F32
+
+    def loss_grad(self, target, mean_elems=None):
+        t, td = self._target(target)
+        B = t.shape[0]
+        me = int(mean_elems) if mean_elems is not None else B * self.pixels
+        _lib.check(self.lib.afr_loss_grad(self._plan, _ptr(t), td, B, me, _ptr(self.loss_accum), _stream()))
+        self._keep_t = t
+
+    def backward(self):
+        _lib.check(self.lib.afr_backward(self._plan, _stream()))
+
+    def adamw_step(self, lr=1e-3, betas=(0.9, 0.99), eps=1e-8, weight_decay=5e-4, grad_scale=1.0):
+        self.t += 1
+        _lib.check(self.lib.afr_adamw_step(self._plan, lr, betas[0], betas[1], eps, weight_decay, self.t, grad_scale, _stream()))
+
+    def train_step(self, x, target, font=None, step=None, lr=1e-3, betas=(0.9, 0.99), eps=1e-8, weight_decay=5e-4,
+                   mean_elems=None, do_step=True):
+        """zero_grad -> forward -> loss -> backward -> AdamW, one C call (model.py:292-310)."""
+        x, font = self._prep_x(x, font)
+        t, td = self._target(target)
+        if isinstance(self.cfg, SheetConfig):
+            B, L = x.shape
+        else:
+            x = x.reshape(-1)
+            B, L = x.shape[0], 1
+        me = int(mean_elems) if mean_elems is not None else B * self.pixels
+        if do_step:
+            self.t += 1
+        st = int(step if step is not None else self.t)
+        _lib.check(self.lib.afr_train_step(self._plan, _ptr(x), _ptr(font), _ptr(t), td, B, L, me, _ptr(self.loss_accum), st,
+                                           int(bool(do_step)), lr, betas[0], betas[1], eps, weight_decay, max(self.t, 1), _stream()))
+        self._keep = (x, font)
+        self._keep_t = t
+
+    def read_loss(self, reset=True):
+        v = float(self.loss_accum.item())
+        if reset:
+            self.loss_accum.zero_()
+        return v
+
+    def error_flags(self):
+        out = C.c_uint32(0)
+        _lib.check(self.lib.afr_error_flags(self._plan, _stream(), C.byref(out)))
+        return out.value
+
+    def debug_read(self, which, index=0):
+        """Copy an internal activation buffer of the last call (u/du, z, dz, glyph activation i) as float32."""
+        code = {"u": _lib.BUF_U, "z": _lib.BUF_Z, "dz": _lib.BUF_DZ, "act": _lib.BUF_ACT + int(index)}[which]
+        dt = torch.bfloat16 if self.dtype in ("bf16", "bfloat16") else torch.float32
+        es = 2 if dt == torch.bfloat16 else 4
+        cap = self.max_batch * max(self.pixels, getattr(self.cfg, "flat_dim", 0), *(getattr(self.cfg, "hidden", (0,))), self.cfg.embed_dim) * es
+        buf = torch.empty(cap, dtype=torch.uint8, device=self.device)
+        n = C.c_size_t()
+        _lib.check(self.lib.afr_debug_copy(self._plan, code, _ptr(buf), cap, C.byref(n), _stream()))
+        torch.cuda.synchronize()
+        return buf[:n.value].view(dt).float()
+
+    # ---------------------------------------------------------------- measurement
+    def profile(self, enable=True):
+        _lib.check(self.lib.afr_profile_dominant(self._plan, int(enable)))
+
+    def profile_read(self):
+        name = C.create_string_buffer(128)
+        ms, fl, by = C.c_double(), C.c_double(), C.c_double()
+        n = C.c_int64()
+        _lib.check(self.lib.afr_profile_read(self._plan, name, 128, C.byref(ms), C.byref(n), C.byref(fl), C.byref(by)))
+        return dict(kernel=name.value.decode(), avg_ms=ms.value, launches=n.value, algo_flops=fl.value, algo_bytes=by.value)

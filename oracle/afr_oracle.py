@@ -19,13 +19,27 @@ import torch
 
 
 # --------------------------------------------------------------------------- sheet model (R0)
-def sheet_forward(P, x, cfg, masks=None):
+def _ident(t):
+    return t
+
+
+def bf16_round(t):
+    """Round-to-nearest-even to bfloat16 and back: lets the oracle mimic the throughput (bf16) mode, which
+    rounds the fc/GEMM operands (weights, activations, du, dz) to bf16 and accumulates in f32."""
+    return t.to(torch.bfloat16).to(t.dtype)
+
+
+def sheet_forward(P, x, cfg, masks=None, rnd=None, relu_mask=None):
     """AttentionFontRenderer.forward, reference model.py:158-204.
 
     P: dict of the 12 state_dict tensors (model.py:136-152).  x: int64 [B, Lin].
     masks: None (eval) or dict(embed=[B,L,E], attn=[B,H,L,L], fc=[B,L,F]) of {0,1}.
+    relu_mask: optional bool [B,L,F] used INSTEAD of (pre > 0): gradients are discontinuous where a
+    pre-activation is within rounding of 0, so a checker that wants tight tolerances takes the masks of the
+    implementation under test and separately checks that they differ from its own only at |pre| ~ 0.
     Returns (y [B,h,w], cache) -- cache holds what sheet_backward needs.
     """
+    rnd = rnd or _ident
     B, Lin = x.shape
     L = min(Lin, cfg.max_length)                                  # model.py:163-164
     x = x[:, :L]
@@ -66,7 +80,8 @@ def sheet_forward(P, x, cfg, masks=None):
     xhat = (r - mu) * rstd
     n = xhat * P["layer_norm.weight"] + P["layer_norm.bias"]
     pre = n @ P["fc1.weight"].t() + P["fc1.bias"]                  # model.py:183
-    f = torch.relu(pre)
+    rmask = (pre > 0) if relu_mask is None else relu_mask
+    f = pre * rmask.to(dt)
     if masks is not None:                                          # model.py:184
         sf = 1.0 / (1.0 - cfg.p_fc)
         fd = f * (masks["fc"].to(dt) * sf)
@@ -75,19 +90,21 @@ def sheet_forward(P, x, cfg, masks=None):
     z = fd.reshape(B, L * F)                                       # model.py:187
     if L < cfg.max_length:                                         # zero-pad branch, :190-193
         z = torch.cat([z, torch.zeros(B, (cfg.max_length - L) * F, dtype=dt)], dim=1)
-    u = z @ P["fc_output.weight"].t() + P["fc_output.bias"]        # model.py:196
+    z = rnd(z)
+    u = rnd(z @ rnd(P["fc_output.weight"]).t() + P["fc_output.bias"])   # model.py:196
     y = u.clamp(0.0, 1.0).reshape(B, cfg.sheet_h, cfg.sheet_w)     # model.py:199-202
     cache = dict(x=x, L=L, e=e, qh=qh, kh=kh, vh=vh, A=A, Ad=Ad, o=o, rstd=rstd, xhat=xhat,
-                 n=n, pre=pre, z=z, u=u, masks=masks)
+                 n=n, pre=pre, rmask=rmask, z=z, u=u, masks=masks)
     return y, cache
 
 
-def sheet_backward(P, cache, du, cfg):
+def sheet_backward(P, cache, du, cfg, rnd=None):
     """Reverse of sheet_forward (what loss.backward() does, model.py:309); SURVEY.md App. A.
 
     du: gradient w.r.t. the pre-clamp output u [B, pixels] (clamp mask already applied).
     Returns dict of the 12 gradients.
     """
+    rnd = rnd or _ident
     c = cache
     B = du.shape[0]
     L, E, H, F = c["L"], cfg.embed_dim, cfg.heads, cfg.fc_dim
@@ -96,12 +113,12 @@ def sheet_backward(P, cache, du, cfg):
     G = {}
     G["fc_output.weight"] = du.t() @ c["z"]
     G["fc_output.bias"] = du.sum(0)
-    dz = du @ P["fc_output.weight"]
+    dz = rnd(du @ rnd(P["fc_output.weight"]))
     dfd = dz[:, :L * F].reshape(B, L, F)
     df = dfd
     if masks is not None:
         df = df * (masks["fc"].to(du.dtype) * (1.0 / (1.0 - cfg.p_fc)))
-    df = df * (c["pre"] > 0).to(du.dtype)                         # ReLU mask (threshold_backward)
+    df = df * c["rmask"].to(du.dtype)                             # ReLU mask (threshold_backward)
     G["fc1.weight"] = df.reshape(-1, F).t() @ c["n"].reshape(-1, E)
     G["fc1.bias"] = df.reshape(-1, F).sum(0)
     dn = df @ P["fc1.weight"]
@@ -145,38 +162,43 @@ def sheet_backward(P, cache, du, cfg):
 
 
 # --------------------------------------------------------------------------- glyph MLP (C1-C4)
-def glyph_forward(P, x, font, cfg):
+def glyph_forward(P, x, font, cfg, rnd=None, relu_masks=None):
     """Per-glyph MLP built from the reference's layer idioms: Embedding gather (model.py:136,167)
     [+ font embedding], Linear+ReLU hidden layers (model.py:148,183), Linear + clamp output
     (model.py:152-156,196-202).  Ancestor: learnings.md:3.  x,font: int64 [B]."""
+    rnd = rnd or _ident
     h = P["embedding.weight"][x]
     if cfg.n_fonts > 0:
         h = h + P["font_embedding.weight"][font]
+    h = rnd(h)
     acts = [h]
     nh = len(cfg.hidden)
-    pres = []
+    pres, rmasks = [], []
     for i in range(nh):
-        pre = h @ P[f"fc{i + 1}.weight"].t() + P[f"fc{i + 1}.bias"]
+        pre = h @ rnd(P[f"fc{i + 1}.weight"]).t() + P[f"fc{i + 1}.bias"]
         pres.append(pre)
-        h = torch.relu(pre)
+        rmasks.append((pre > 0) if relu_masks is None else relu_masks[i])
+        h = rnd(pre * rmasks[i].to(pre.dtype))
         acts.append(h)
-    u = h @ P["fc_output.weight"].t() + P["fc_output.bias"]
+    u = rnd(h @ rnd(P["fc_output.weight"]).t() + P["fc_output.bias"])
     y = u.clamp(0.0, 1.0).reshape(-1, cfg.out_h, cfg.out_w)
-    return y, dict(x=x, font=font, acts=acts, pres=pres, u=u)
+    return y, dict(x=x, font=font, acts=acts, pres=pres, rmasks=rmasks, u=u)
 
 
-def glyph_backward(P, cache, du, cfg):
+def glyph_backward(P, cache, du, cfg, rnd=None):
+    rnd = rnd or _ident
     G = {}
     acts, pres = cache["acts"], cache["pres"]
     nh = len(cfg.hidden)
     G["fc_output.weight"] = du.t() @ acts[nh]
     G["fc_output.bias"] = du.sum(0)
-    d = du @ P["fc_output.weight"]
+    d = du @ rnd(P["fc_output.weight"])
     for i in reversed(range(nh)):
-        d = d * (pres[i] > 0).to(d.dtype)
+        d = rnd(d * cache["rmasks"][i].to(d.dtype))
         G[f"fc{i + 1}.weight"] = d.t() @ acts[i]
         G[f"fc{i + 1}.bias"] = d.sum(0)
-        d = d @ P[f"fc{i + 1}.weight"]
+        d = d @ rnd(P[f"fc{i + 1}.weight"])
+    d = rnd(d)
     dEmb = torch.zeros_like(P["embedding.weight"])
     dEmb.index_add_(0, cache["x"], d)
     G["embedding.weight"] = dEmb
@@ -188,7 +210,7 @@ def glyph_backward(P, cache, du, cfg):
 
 
 # --------------------------------------------------------------------------- loss / optimiser
-def mse_loss_grad(u, target, total_elems=None):
+def mse_loss_grad(u, target, total_elems=None, clamp_mask=None):
     """F.mse_loss(clamp(u,0,1), target) and its gradient w.r.t. u (model.py:156,268-270).
     clamp passes gradient where 0 <= u <= 1 inclusive (torch clamp_backward).  total_elems
     overrides the mean's denominator (global batch * pixels under data parallelism)."""
@@ -198,7 +220,8 @@ def mse_loss_grad(u, target, total_elems=None):
     y = u2.clamp(0.0, 1.0)
     diff = y - t2
     loss = (diff * diff).sum() / n
-    du = (2.0 / n) * diff * ((u2 >= 0) & (u2 <= 1)).to(u2.dtype)
+    cm = ((u2 >= 0) & (u2 <= 1)) if clamp_mask is None else clamp_mask.reshape(u2.shape)
+    du = (2.0 / n) * diff * cm.to(u2.dtype)
     return loss, du
 
 

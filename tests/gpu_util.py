@@ -1,0 +1,60 @@
+"""Helpers for the -m gpu parity tests: everything goes through the C ABI (ctypes), torch only holds memory."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from ai_font_renderer_amd import _lib
+
+
+def dev(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a)) if isinstance(a, np.ndarray) else a
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.cuda().contiguous()
+
+
+def ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def gemm(dtype, A_log, B_log, a_kstrided=False, b_kstrided=False, bias=None, relu=False, aux=None, out_bf16=False, splitk=1):
+    """C[m][n] = sum_k A_log[m][k] * B_log[n][k] through afr_op_gemm, with the operands stored in the
+    requested orientation.  dtype 'f32' | 'bf16'.  Returns a float32 CPU tensor."""
+    lib = _lib.lib()
+    M, K = A_log.shape
+    N = B_log.shape[0]
+    tdt = torch.float32 if dtype == "f32" else torch.bfloat16
+    A = dev(A_log.t().contiguous() if a_kstrided else A_log, tdt)
+    B = dev(B_log.t().contiguous() if b_kstrided else B_log, tdt)
+    flags = 0
+    if a_kstrided:
+        flags |= _lib.GEMM_A_KSTRIDED
+    if b_kstrided:
+        flags |= _lib.GEMM_B_KSTRIDED
+    bias_d = None
+    if bias is not None:
+        flags |= _lib.GEMM_BIAS
+        bias_d = dev(bias, torch.float32)
+    if relu:
+        flags |= _lib.GEMM_RELU
+    aux_d = None
+    if aux is not None:
+        flags |= _lib.GEMM_RELU_MASK
+        aux_d = dev(aux, tdt)
+    if out_bf16:
+        flags |= _lib.GEMM_OUT_BF16
+    Cd = torch.full((splitk, M, N), float("nan"), dtype=torch.bfloat16 if out_bf16 else torch.float32, device="cuda")
+    _lib.check(lib.afr_op_gemm(_lib.AFR_F32 if dtype == "f32" else _lib.AFR_BF16, flags, ptr(A), ptr(B), ptr(Cd), ptr(bias_d),
+                               ptr(aux_d), M, N, K, M if a_kstrided else K, N if b_kstrided else K, N, N, splitk, stream()))
+    if splitk > 1:
+        out = torch.empty(M, N, dtype=torch.float32, device="cuda")
+        _lib.check(lib.afr_op_reduce(ptr(out), ptr(Cd), splitk, M * N, M * N, 1.0, 0, stream()))
+        torch.cuda.synchronize()
+        return out.cpu()
+    torch.cuda.synchronize()
+    return Cd[0].float().cpu()
