@@ -51,6 +51,7 @@ SIGNATURES = {
     "afr_error_flags": (_i32, [_vp, _vp, C.POINTER(C.c_uint32)]),
     "afr_profile_dominant": (_i32, [_vp, _i32]),
     "afr_profile_read": (_i32, [_vp, C.c_char_p, _i32, C.POINTER(C.c_double), C.POINTER(_i64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "afr_profile_dump": (_i32, [_vp, C.c_char_p, _i32]),
     "afr_debug_copy": (_i32, [_vp, _i32, _vp, _sz, C.POINTER(_sz), _vp]),
     "afr_op_gemm": (_i32, [_i32, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "afr_op_reduce": (_i32, [_vp, _vp, _i32, _i64, _i64, _f32, _i32, _vp]),

@@ -66,7 +66,8 @@ struct afr_plan {
     uint64_t last_step = 0;
     bool have_du = false;
     // profiling
-    bool prof_on = false;
+    int prof_mode = 0;      // 0 off, 1 every launch, 2 only prof_only
+    int prof_only = -1;
     std::vector<ProfRec> prof;
     std::vector<std::string> prof_tags;
     std::vector<hipEvent_t> ev_pool;
@@ -259,32 +260,52 @@ static int tag_id(afr_plan* p, const char* tag) {
 }
 struct ProfScope {
     afr_plan* p; hipStream_t s; ProfRec r; bool on;
-    ProfScope(afr_plan* p_, hipStream_t s_, const char* tag, double flops, double bytes) : p(p_), s(s_), on(p_->prof_on) {
+    ProfScope(afr_plan* p_, hipStream_t s_, const char* tag, double flops, double bytes) : p(p_), s(s_), on(p_->prof_mode != 0) {
         if (!on) return;
-        r.tag = tag_id(p, tag); r.flops = flops; r.bytes = bytes; r.a = ev_get(p); r.b = ev_get(p);
+        r.tag = tag_id(p, tag);
+        if (p->prof_mode == 2 && r.tag != p->prof_only) { on = false; return; } r.flops = flops; r.bytes = bytes; r.a = ev_get(p); r.b = ev_get(p);
         (void)hipEventRecord(r.a, s);
     }
     ~ProfScope() { if (on) { (void)hipEventRecord(r.b, s); p->prof.push_back(r); } }
 };
-extern "C" int afr_profile_dominant(afr_plan* p, int enable) {
-    if (!p) return fail(AFR_EINVAL, "null plan");
-    for (auto& r : p->prof) { p->ev_pool.push_back(r.a); p->ev_pool.push_back(r.b); }
-    p->prof.clear();
-    p->prof_on = enable != 0;
-    return AFR_OK;
-}
-extern "C" int afr_profile_read(afr_plan* p, char* name, int cap, double* avg_ms, int64_t* launches, double* flops,
-                                double* bytes) {
-    if (!p) return fail(AFR_EINVAL, "null plan");
-    if (p->prof.empty()) return fail(AFR_ESTATE, "no profiled launches recorded");
-    std::vector<double> tot(p->prof_tags.size(), 0.0), fl(p->prof_tags.size(), 0.0), by(p->prof_tags.size(), 0.0);
-    std::vector<int64_t> cnt(p->prof_tags.size(), 0);
+static int prof_totals(afr_plan* p, std::vector<double>& tot, std::vector<double>& fl, std::vector<double>& by,
+                       std::vector<int64_t>& cnt) {
+    const size_t n = p->prof_tags.size();
+    tot.assign(n, 0.0); fl.assign(n, 0.0); by.assign(n, 0.0); cnt.assign(n, 0);
     for (auto& r : p->prof) {
         HIPCHK(hipEventSynchronize(r.b));
         float ms = 0.f;
         HIPCHK(hipEventElapsedTime(&ms, r.a, r.b));
         tot[r.tag] += ms; fl[r.tag] += r.flops; by[r.tag] += r.bytes; cnt[r.tag]++;
     }
+    return AFR_OK;
+}
+extern "C" int afr_profile_dominant(afr_plan* p, int mode) {
+    if (!p) return fail(AFR_EINVAL, "null plan");
+    if (mode == 2) {     // keep timing only the kernel that dominated the launches recorded so far
+        if (p->prof.empty() && p->prof_only < 0)
+            return fail(AFR_ESTATE, "mode 2 needs a mode-1 recording to pick the dominant kernel from");
+        if (!p->prof.empty() && p->prof_mode == 1) {
+            std::vector<double> tot, fl, by; std::vector<int64_t> cnt;
+            int rc = prof_totals(p, tot, fl, by, cnt);
+            if (rc) return rc;
+            size_t best = 0;
+            for (size_t i = 1; i < tot.size(); ++i) if (tot[i] > tot[best]) best = i;
+            p->prof_only = (int)best;
+        }
+    }
+    for (auto& r : p->prof) { p->ev_pool.push_back(r.a); p->ev_pool.push_back(r.b); }
+    p->prof.clear();
+    p->prof_mode = mode;
+    return AFR_OK;
+}
+extern "C" int afr_profile_read(afr_plan* p, char* name, int cap, double* avg_ms, int64_t* launches, double* flops,
+                                double* bytes) {
+    if (!p) return fail(AFR_EINVAL, "null plan");
+    if (p->prof.empty()) return fail(AFR_ESTATE, "no profiled launches recorded");
+    std::vector<double> tot, fl, by; std::vector<int64_t> cnt;
+    int rc = prof_totals(p, tot, fl, by, cnt);
+    if (rc) return rc;
     size_t best = 0;
     for (size_t i = 1; i < tot.size(); ++i) if (tot[i] > tot[best]) best = i;
     if (name && cap > 0) { strncpy(name, p->prof_tags[best].c_str(), cap - 1); name[cap - 1] = 0; }
@@ -292,6 +313,21 @@ extern "C" int afr_profile_read(afr_plan* p, char* name, int cap, double* avg_ms
     if (launches) *launches = cnt[best];
     if (flops) *flops = fl[best] / (double)cnt[best];
     if (bytes) *bytes = by[best] / (double)cnt[best];
+    return AFR_OK;
+}
+
+extern "C" int afr_profile_dump(afr_plan* p, char* buf, int cap) {
+    if (!p || !buf || cap <= 0) return fail(AFR_EINVAL, "bad arguments");
+    std::vector<double> tot, fl, by; std::vector<int64_t> cnt;
+    int rc = prof_totals(p, tot, fl, by, cnt);
+    if (rc) return rc;
+    int n = 0;
+    buf[0] = 0;
+    for (size_t i = 0; i < tot.size() && n < cap - 1; ++i) {
+        if (!cnt[i]) continue;
+        n += snprintf(buf + n, cap - n, "%s\t%lld\t%.6f\t%.6f\t%.6g\t%.6g\n", p->prof_tags[i].c_str(), (long long)cnt[i], tot[i],
+                      tot[i] / cnt[i], fl[i] / cnt[i], by[i] / cnt[i]);
+    }
     return AFR_OK;
 }
 

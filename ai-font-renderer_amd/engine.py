@@ -202,8 +202,19 @@ class Engine:
         return buf[:n.value].view(dt).float()
 
     # ---------------------------------------------------------------- measurement
-    def profile(self, enable=True):
-        _lib.check(self.lib.afr_profile_dominant(self._plan, int(enable)))
+    def profile(self, mode=1):
+        """0 off, 1 time every launch, 2 time only the kernel that dominated the mode-1 recording."""
+        _lib.check(self.lib.afr_profile_dominant(self._plan, int(mode)))
+
+    def profile_table(self):
+        buf = C.create_string_buffer(8192)
+        _lib.check(self.lib.afr_profile_dump(self._plan, buf, 8192))
+        rows = []
+        for line in buf.value.decode().strip().split("\n"):
+            if line:
+                k, n, tot, avg, fl, by = line.split("\t")
+                rows.append(dict(kernel=k, launches=int(n), total_ms=float(tot), avg_ms=float(avg), algo_flops=float(fl), algo_bytes=float(by)))
+        return sorted(rows, key=lambda r: -r["total_ms"])
 
     def profile_read(self):
         name = C.create_string_buffer(128)

@@ -1,0 +1,45 @@
+"""Data parallelism for the training step: one process per GPU, torch.distributed over RCCL/xGMI.
+
+The reference is single-device (model.py:95-106); sharding is new.  Samples are independent, so
+the batch is cut into contiguous row slices, one per rank, with NO data-path collective; the only exchange per
+step is one sum all-reduce of the flat gradient buffer (all parameters of state_dict() live in one contiguous
+float32 buffer, so it is a single RCCL call).  Every shard divides its loss by the GLOBAL element count
+(`mean_elems`), so the summed gradients equal the full-batch gradients exactly, also for uneven last batches
+(192 / 304 rows in the reference's loaders).  Parameters, AdamW moments and the step counter are replicated;
+each rank draws its own dropout stream (rank is part of the counter-hash key).
+
+`engine` is anything with train_step(x, target, font=, mean_elems=, do_step=), flat_grads, adamw_step(**hyper)
+and loss_accum: the HIP Engine in production; tests drive the same logic on CPU (gloo) with a stand-in.
+"""
+
+
+def shard_rows(n_rows, rank, world):
+    """Contiguous slice of the global batch owned by `rank`: sizes differ by at most one row."""
+    base, rem = divmod(n_rows, world)
+    start = rank * base + min(rank, rem)
+    return slice(start, start + base + (1 if rank < rem else 0))
+
+
+class DataParallelStepper:
+    def __init__(self, engine, dist=None, world=1):
+        self.engine, self.dist, self.world = engine, dist, int(world)
+
+    def step(self, x, target, font=None, mean_elems=None, **hyper):
+        """One optimiser step on this rank's shard.  mean_elems = global_rows * pixels."""
+        eng = self.engine
+        if self.world == 1 or self.dist is None:
+            eng.train_step(x, target, font=font, mean_elems=mean_elems, do_step=True, **hyper)
+            return
+        eng.train_step(x, target, font=font, mean_elems=mean_elems, do_step=False, **hyper)
+        self.dist.all_reduce(eng.flat_grads)                  # sum over ranks; RCCL ring/tree over xGMI
+        eng.adamw_step(**{k: v for k, v in hyper.items() if k in ("lr", "betas", "eps", "weight_decay")})
+
+    def global_loss(self, reset=True):
+        """Sum of the shards' loss shares == the global mean loss (each share is already / mean_elems)."""
+        eng = self.engine
+        acc = eng.loss_accum.clone()
+        if self.world > 1 and self.dist is not None:
+            self.dist.all_reduce(acc)
+        if reset:
+            eng.loss_accum.zero_()
+        return float(acc.item())

@@ -1,0 +1,211 @@
+#!/usr/bin/env python3
+"""bench.py -- glyphs/sec of one full training step (forward + MSE + backward + AdamW) of the hot path.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3|c2|c1|r0] [--dtype bf16|f32]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W          (one rank per GPU, RCCL)
+
+Workloads (BASELINE.json configs) -- per-GPU batch is fixed, so scaling is WEAK:
+  c3 (default)  32x32 glyphs, Emb+FontEmb -> 1024 -> 1024 -> 1024, bf16, 8192 glyphs per GPU.  This is
+                configs[2], the largest single-GPU configuration, and the per-GPU shard of configs[3]
+                (65536 glyphs over 8 GPUs), the configuration the metric's 1/2/4/8 scaling is quoted on.
+  c2            16x16 glyphs, hidden 256, bf16, 4096 glyphs (configs[1]; launch-latency bound)
+  c1            same net, fp32, 95 glyphs (configs[0], the CPU-runnable case)
+  r0            the reference's own AttentionFontRenderer (80x240 sheets of <=100 chars), 1024 sheets per GPU
+Inputs (codes, font ids, uint8 target bitmaps) are synthetic (counter hash / seeded text generator) and resident in
+HBM before the timed region.  A step = the loop body of reference model.py:292-310.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from ai_font_renderer_amd import synth  # noqa: E402
+from ai_font_renderer_amd.config import WORKLOADS, SheetConfig  # noqa: E402
+
+PEAK = {"bf16": 2500.0, "f32": 157.3}        # dense MFMA TFLOP/s, MI355X_MICROARCH.md chip table
+HBM_PEAK_GBS = 8000.0
+DESCR = {
+    "c3": "C3: 32x32 glyph MLP 32->1024->1024->1024, char+font embedding, batch 8192/GPU (BASELINE configs[2]; per-GPU shard of configs[3])",
+    "c2": "C2: 16x16 glyph MLP 32->256->256, batch 4096 (BASELINE configs[1])",
+    "c1": "C1: 16x16 glyph MLP 32->256->256, fp32, batch 95 (BASELINE configs[0])",
+    "r0": "R0: reference AttentionFontRenderer, 100 chars -> 80x240 sheet, batch 1024/GPU",
+}
+DEFAULT_DTYPE = {"c3": "bf16", "c2": "bf16", "c1": "f32", "r0": "bf16"}
+DEFAULT_STEPS = {"c3": (200, 20), "c2": (500, 50), "c1": (500, 50), "r0": (30, 5)}
+
+
+def make_inputs(name, cfg, B, rank):
+    """Synthetic batch for this rank: rows [rank*B, (rank+1)*B) of the global batch."""
+    if isinstance(cfg, SheetConfig):
+        strings = synth.dataset_strings(B, first_seed=42 + rank * B)
+        x = synth.encode_strings(strings, cfg.max_length)
+        t = synth.synth_sheet_targets(B, cfg.sheet_h, cfg.sheet_w, tensor_id=940 + rank)
+        return torch.from_numpy(x), None, torch.from_numpy(t)
+    i = np.arange(rank * B, (rank + 1) * B)
+    x = (32 + (i % 95)).astype(np.int64)                              # the 95 printable ASCII codes, repeated
+    font = ((i // 95) % max(cfg.n_fonts, 1)).astype(np.int64)
+    t = synth.hash_u8(950 + rank, (B, cfg.out_h, cfg.out_w))
+    return torch.from_numpy(x), (torch.from_numpy(font) if cfg.n_fonts > 0 else None), torch.from_numpy(t)
+
+
+def host_cores():
+    """CPU cores this process may really use: cgroup quota, else affinity mask (a GPU box gives each GPU a share)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return int(os.environ.get("AFR_CPU_THREADS", min(n, 16)))
+
+
+def cpu_baseline(name, cfg, B, budget_s=15.0):
+    """The oracle (a CPU port of the reference's step in plain torch ops) timed on this box's host cores."""
+    from oracle import afr_oracle as oracle            # checker / baseline only -- never on the product path
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    x, font, t = make_inputs(name, cfg, B, 0)
+    tgt = t.to(torch.float32) / 255.0
+    P = {k: torch.from_numpy(v) for k, v in synth.make_params(cfg).items()}
+    M = {k: torch.zeros_like(v) for k, v in P.items()}
+    V = {k: torch.zeros_like(v) for k, v in P.items()}
+    masks = None
+    if isinstance(cfg, SheetConfig):
+        masks = {k: torch.from_numpy(v) for k, v in synth.sheet_dropout_masks(cfg, B, cfg.max_length, 42, 1).items()}
+    times = []
+    t_start = time.perf_counter()
+    step = 0
+    while True:
+        t0 = time.perf_counter()
+        _, _, P, M, V = oracle.train_step(P, M, V, step + 1, x, tgt, cfg, font=font, masks=masks)
+        dt = time.perf_counter() - t0
+        step += 1
+        if step > 1:
+            times.append(dt)                                          # first step is warm-up
+        if (time.perf_counter() - t_start > budget_s and len(times) >= 2) or len(times) >= 20:
+            break
+    med = float(np.median(times))
+    return {"value": B / med, "unit": "glyphs/s", "cores": cores, "kind": "port",
+            "sample": f"{len(times)} steps of batch {B} after 1 warm-up, median step {med * 1e3:.1f} ms, fp32, torch {torch.__version__} CPU ops"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
+    ap.add_argument("--dtype", default=None, choices=["bf16", "f32"])
+    ap.add_argument("--batch", type=int, default=None, help="per-GPU batch override (changes the workload: for experiments only)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--table", action="store_true", help="also print the per-kernel time table to stderr")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N>1 must be launched with python -m torch.distributed.run --nproc-per-node N")
+        args.gpus = world
+    name = args.workload
+    cfg = WORKLOADS[name]["cfg"]
+    B = args.batch or WORKLOADS[name]["batch"]
+    dtype = args.dtype or DEFAULT_DTYPE[name]
+    K = args.steps if args.steps is not None else DEFAULT_STEPS[name][0]
+    W = args.warmup if args.warmup is not None else DEFAULT_STEPS[name][1]
+
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # nccl == RCCL on ROCm
+
+    from ai_font_renderer_amd.engine import Engine
+    from ai_font_renderer_amd.parallel import DataParallelStepper
+    eng = Engine(cfg, dtype=dtype, max_batch=B, rank=rank)
+    eng.load_params(synth.make_params(cfg))                           # same formula-generated weights on every rank
+    x, font, tgt = make_inputs(name, cfg, B, rank)
+    x, tgt = x.cuda(), tgt.cuda()
+    font = font.cuda() if font is not None else None
+    stepper = DataParallelStepper(eng, dist, world)
+    mean_elems = world * B * cfg.pixels
+
+    def run(n):
+        for _ in range(n):
+            stepper.step(x, tgt, font, mean_elems)
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # warm-up; its last steps run with every launch timed, to find the dominant kernel
+    run(max(W - 3, 1))
+    torch.cuda.synchronize()
+    eng.profile(1)
+    run(min(W, 3) if W > 0 else 1)
+    torch.cuda.synchronize()
+    table = eng.profile_table()
+    eng.profile(2)                                                    # timed region: events around the dominant kernel only
+    fence()
+    t0 = time.perf_counter()
+    run(K)
+    fence()
+    elapsed = time.perf_counter() - t0
+    dom = eng.profile_read()
+    eng.profile(0)
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    loss = eng.read_loss() / max(K + W, 1)
+    if eng.error_flags():
+        raise SystemExit("device error flag set (embedding index out of range)")
+
+    if rank == 0:
+        value = world * B * K / elapsed
+        if dom["algo_flops"] > 0:
+            ach = dom["algo_flops"] / (dom["avg_ms"] * 1e-3) / 1e12
+            roof = {"bound": "mfma", "kernel": dom["kernel"], "achieved": ach, "peak": PEAK[dtype], "unit": "TFLOP/s",
+                    "frac": ach / PEAK[dtype], "traffic": None, "avg_launch_ms": dom["avg_ms"], "launches": dom["launches"],
+                    "algo_flops_per_launch": dom["algo_flops"]}
+        else:
+            ach = dom["algo_bytes"] / (dom["avg_ms"] * 1e-3) / 1e9
+            roof = {"bound": "hbm", "kernel": dom["kernel"], "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": ach / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": dom["avg_ms"], "launches": dom["launches"],
+                    "algo_bytes_per_launch": dom["algo_bytes"]}
+        out = {
+            "metric": "glyphs/sec training (batch fwd+bwd+step)", "value": value, "unit": "glyphs/s", "n_gpus": world,
+            "steps": K, "warmup": W, "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": dtype, "data": "synthetic",
+            "config": {"workload": DESCR[name], "per_gpu_batch": B, "global_batch": world * B,
+                       "parallelism": f"dp{world}" if world > 1 else "single", "params": int(sum(n for _, _, _, n in eng.layout)),
+                       "mean_loss": loss},
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(name, cfg, B)
+            out["cpu_baseline"]["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
+        if args.table:
+            for r in table:
+                print(f"{r['kernel']:24s} n={r['launches']:4d} avg={r['avg_ms'] * 1e3:9.1f} us total={r['total_ms']:9.3f} ms", file=sys.stderr)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

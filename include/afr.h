@@ -122,10 +122,14 @@ int afr_train_step(afr_plan* plan, const int64_t* x, const int64_t* font, const 
 int afr_error_flags(afr_plan* plan, void* stream, uint32_t* flags_out);
 
 /* Name and average duration (ms, hipEvent-timed on the launch stream) of the plan's dominant
- * kernel over the calls since the last reset; bench.py's roofline leg.  enable!=0 starts timing. */
-int afr_profile_dominant(afr_plan* plan, int enable);
+ * kernel over the calls since the last reset; bench.py's roofline leg.  mode 0: off; 1: time every
+ * launch (to find the dominant kernel); 2: from now on time only the kernel that dominated the
+ * mode-1 recording (two events per launch of that kernel: cheap enough for a timed region). */
+int afr_profile_dominant(afr_plan* plan, int mode);
 int afr_profile_read(afr_plan* plan, char* name, int name_cap, double* avg_ms, int64_t* launches,
                      double* algo_flops, double* algo_bytes);
+/* Text table of everything recorded: one "kernel\tlaunches\ttotal_ms\tavg_ms\tflops\tbytes" line per kernel. */
+int afr_profile_dump(afr_plan* plan, char* buf, int cap);
 
 /* Inspection for stage-by-stage validation: copy one internal activation buffer of the last call (in the plan's
  * activation dtype: f32, or bf16 in AFR_BF16 mode) to dst (device or host pointer).  *bytes_out = bytes copied. */

@@ -1,0 +1,97 @@
+"""CPU, gloo, world_size 2: the data-parallel step logic (ai_font_renderer_amd.parallel) driven with an
+oracle-backed stand-in engine.  Checks that sharded steps reproduce the single-process full-batch step:
+same summed gradients (global-mean weighting, uneven shards) and identical parameters on every rank."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from .util import ROOT, GlyphConfig, glyph_inputs, oracle, synth, tparams
+
+
+class OracleEngine:
+    """Engine look-alike on CPU: flat_grads / loss_accum / train_step / adamw_step over the oracle."""
+
+    def __init__(self, cfg):
+        from ai_font_renderer_amd.config import flat_layout
+        self.cfg = cfg
+        self.table, n = flat_layout(cfg)
+        self.P = tparams(cfg)
+        self.M = {k: torch.zeros_like(v) for k, v in self.P.items()}
+        self.V = {k: torch.zeros_like(v) for k, v in self.P.items()}
+        self.flat_grads = torch.zeros(n)
+        self.loss_accum = torch.zeros(1)
+        self.t = 0
+
+    def train_step(self, x, target, font=None, mean_elems=None, do_step=True, **hyper):
+        _, cache = oracle.glyph_forward(self.P, x, font, self.cfg)
+        loss, du = oracle.mse_loss_grad(cache["u"], target.float() / 255.0, total_elems=mean_elems)
+        G = oracle.glyph_backward(self.P, cache, du, self.cfg)
+        self.flat_grads.zero_()
+        for name, shape, off, n in self.table:
+            self.flat_grads[off:off + n] = G[name].reshape(-1)
+        self.loss_accum += loss
+        if do_step:
+            self.adamw_step(**hyper)
+
+    def adamw_step(self, **hyper):
+        self.t += 1
+        for name, shape, off, n in self.table:
+            g = self.flat_grads[off:off + n].view(shape)
+            self.P[name], self.M[name], self.V[name] = oracle.adamw_step(self.P[name], g, self.M[name], self.V[name], self.t)
+
+
+CFG = GlyphConfig(hidden=(24, 16), out_h=4, out_w=4, n_fonts=2)
+ROWS = 37          # uneven over 2 ranks: 19 + 18
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from ai_font_renderer_amd.parallel import DataParallelStepper, shard_rows
+    torch.set_num_threads(1)
+    x, font, t = glyph_inputs(CFG, ROWS)
+    sl = shard_rows(ROWS, rank, world)
+    eng = OracleEngine(CFG)
+    st = DataParallelStepper(eng, dist, world)
+    for _ in range(3):
+        st.step(torch.from_numpy(x[sl]), torch.from_numpy(t[sl]), torch.from_numpy(font[sl]), mean_elems=ROWS * CFG.pixels)
+    loss = st.global_loss()
+    q.put((rank, {k: v.numpy() for k, v in eng.P.items()}, eng.flat_grads.numpy().copy(), loss))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_data_parallel_equals_full_batch():
+    from ai_font_renderer_amd.parallel import DataParallelStepper, shard_rows
+    assert [shard_rows(37, r, 2) for r in range(2)] == [slice(0, 19), slice(19, 37)]
+    assert sum(s.stop - s.start for s in (shard_rows(8192 * 8 + 5, r, 8) for r in range(8))) == 8192 * 8 + 5
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # single-process full batch
+    x, font, t = glyph_inputs(CFG, ROWS)
+    eng = OracleEngine(CFG)
+    st = DataParallelStepper(eng, None, 1)
+    for _ in range(3):
+        st.step(torch.from_numpy(x), torch.from_numpy(t), torch.from_numpy(font), mean_elems=ROWS * CFG.pixels)
+    full_loss = st.global_loss()
+    for rank, P, g, loss in res:
+        assert abs(loss - full_loss) < 1e-6 * full_loss
+        assert np.abs(g - eng.flat_grads.numpy()).max() < 1e-6 * np.abs(g).max()
+        for k in P:
+            assert np.abs(P[k] - eng.P[k].numpy()).max() < 2e-6, (rank, k)
+    for k in res[0][1]:                                     # replicas stay bit-identical to each other
+        assert np.array_equal(res[0][1][k], res[1][1][k]), k
