@@ -54,7 +54,7 @@ struct afr_plan {
     size_t o_d[2] = {0, 0};        // glyph: ping-pong d buffers
     size_t slab_w_elems = 0;
     // glyph layer table
-    struct Layer { int N, K; int64_t w_off, b_off; };
+    struct Layer { int N, K; int64_t w_off, b_off; int sk = 1; size_t o_slab_w = 0, o_slab_b = 0; };
     std::vector<Layer> layers;
     int64_t emb_off = 0, font_off = 0;
     // sheet offsets
@@ -145,14 +145,14 @@ extern "C" int afr_plan_create(const afr_config* c, afr_plan** out) {
         const size_t Kz = (size_t)L * F;
         if (c->dtype == AFR_BF16) p->o_shadow = carve((size_t)p->total * 2);
         p->o_err = carve(256);
-        p->o_loss = carve(1024 * sizeof(float));
+        p->o_loss = carve(1040 * sizeof(float));
         p->o_z = carve(B * Kz * ab);
         p->o_u = carve(B * Pix * ab);
         p->o_dz = carve(B * Kz * ab);
-        const int sk = choose_splitk(Pix, (int)Kz, (int)B);
-        p->slab_w_elems = sk > 1 ? (size_t)sk * Pix * Kz : 0;
-        p->o_slab_w = carve(p->slab_w_elems * sizeof(float));
-        p->o_slab_c = carve((size_t)afr_colsum_splits((long long)B) * Pix * sizeof(float));
+        afr_plan::Layer ly; ly.N = Pix; ly.K = (int)Kz; ly.w_off = p->s_wout; ly.b_off = p->s_bout;
+        ly.sk = choose_splitk(Pix, (int)Kz, (int)B);
+        if (ly.sk > 1) { ly.o_slab_w = carve((size_t)ly.sk * Pix * Kz * sizeof(float)); ly.o_slab_b = carve((size_t)ly.sk * Pix * sizeof(float)); }
+        p->layers.push_back(ly);
         p->o_slab_e = carve((size_t)afr_sheet_blocks((int)B) * (size_t)p->s_wout * sizeof(float));
     } else if (c->kind == AFR_KIND_GLYPH) {
         if (c->n_hidden < 0 || c->n_hidden > AFR_MAX_HIDDEN) { delete p; return fail(AFR_EINVAL, "n_hidden out of range"); }
@@ -182,7 +182,7 @@ extern "C" int afr_plan_create(const afr_config* c, afr_plan** out) {
         p->font_off = c->n_fonts > 0 ? off_of(p, "font_embedding.weight") : -1;
         if (c->dtype == AFR_BF16) p->o_shadow = carve((size_t)p->total * 2);
         p->o_err = carve(256);
-        p->o_loss = carve(1024 * sizeof(float));
+        p->o_loss = carve(1040 * sizeof(float));
         size_t maxw = (size_t)E, maxn = 0;
         p->o_act.push_back(carve(B * E * ab));
         for (int i = 0; i < c->n_hidden; ++i) {
@@ -192,15 +192,11 @@ extern "C" int afr_plan_create(const afr_config* c, afr_plan** out) {
         p->o_u = carve(B * Pix * ab);
         p->o_d[0] = carve(B * maxw * ab);
         p->o_d[1] = carve(B * maxw * ab);
-        size_t slab = 0;
-        for (const auto& l : p->layers) {
-            const int sk = choose_splitk(l.N, l.K, (int)B);
-            if (sk > 1 && (size_t)sk * l.N * l.K > slab) slab = (size_t)sk * l.N * l.K;
+        for (auto& l : p->layers) {
+            l.sk = choose_splitk(l.N, l.K, (int)B);
+            if (l.sk > 1) { l.o_slab_w = carve((size_t)l.sk * l.N * l.K * sizeof(float)); l.o_slab_b = carve((size_t)l.sk * l.N * sizeof(float)); }
             if ((size_t)l.N > maxn) maxn = (size_t)l.N;
         }
-        p->slab_w_elems = slab;
-        p->o_slab_w = carve(slab * sizeof(float));
-        p->o_slab_c = carve((size_t)afr_colsum_splits((long long)B) * maxn * sizeof(float));
         p->o_slab_e = carve((size_t)afr_embed_bwd_blocks((int)B) * (size_t)(c->vocab + c->n_fonts) * E * sizeof(float));
     } else {
         delete p;
@@ -338,8 +334,9 @@ static inline const void* weight_ptr(const afr_plan* p, int64_t off) {
 }
 static int run_gemm(afr_plan* p, hipStream_t s, int flags, const void* A, const void* B, void* C, const float* bias,
                     const void* aux, int M, int N, int K, int lda, int ldb, int ldc, int ldaux, int splitk,
-                    long long slab_stride) {
+                    long long slab_stride, float* colsum = nullptr, long long colsum_stride = 0) {
     GemmParams g;
+    g.colsum = colsum; g.colsum_stride = colsum_stride;
     g.A = A; g.B = B; g.C = C; g.bias = bias; g.aux = aux;
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldaux = ldaux;
     g.flags = flags; g.splitk = splitk; g.slab_stride = slab_stride;
@@ -350,25 +347,28 @@ static int run_gemm(afr_plan* p, hipStream_t s, int flags, const void* A, const 
     HIPCHK(afr_launch_gemm(p->cfg.dtype, g, s));
     return AFR_OK;
 }
-// dW[N][K] = dy[B][N]^T . a[B][K], reduced over the batch; split-K partial slabs when the output is small
-static int run_dw(afr_plan* p, hipStream_t s, const void* dy, const void* a, int Bn, int N, int K, float* Gw) {
-    const int sk = choose_splitk(N, K, Bn);
+// dW[N][K] = dy[B][N]^T . a[B][K] and db[N] = sum_b dy, reduced over the batch in ONE GEMM launch (the bias gradient
+// is the column sum of the A tiles the kernel already stages).  Small outputs use split-K partial slabs, summed later
+// by the grouped reduce; large ones (fc_output of the sheet model) write the gradient buffer directly.
+static int run_dw(afr_plan* p, hipStream_t s, const afr_plan::Layer& l, const void* dy, const void* a, int Bn, RTable& rt) {
     const int fl = AFR_GEMM_A_KSTRIDED | AFR_GEMM_B_KSTRIDED;
-    if (sk == 1) return run_gemm(p, s, fl, dy, a, Gw, nullptr, nullptr, N, K, Bn, N, K, K, 0, 1, 0);
-    float* slabs = (float*)(p->ws + p->o_slab_w);
-    if ((size_t)sk * N * K > p->slab_w_elems) return fail(AFR_ESTATE, "split-K slab space too small");
-    int rc = run_gemm(p, s, fl, dy, a, slabs, nullptr, nullptr, N, K, Bn, N, K, K, 0, sk, (long long)N * K);
+    const int N = l.N, K = l.K;
+    int sk = choose_splitk(N, K, Bn);
+    if (sk > l.sk) sk = l.sk;
+    if (sk == 1) return run_gemm(p, s, fl, dy, a, p->G + l.w_off, nullptr, nullptr, N, K, Bn, N, K, K, 0, 1, 0, p->G + l.b_off, 0);
+    float* sw = (float*)(p->ws + l.o_slab_w);
+    float* sb = (float*)(p->ws + l.o_slab_b);
+    int rc = run_gemm(p, s, fl, dy, a, sw, nullptr, nullptr, N, K, Bn, N, K, K, 0, sk, (long long)N * K, sb, N);
     if (rc) return rc;
-    ProfScope ps(p, s, "reduce_slabs", 0.0, 4.0 * (double)N * K * (sk + 1));
-    HIPCHK(afr_launch_reduce(Gw, slabs, sk, (long long)N * K, (long long)N * K, 1.f, 0, s));
+    afr_rtable_add(rt, p->G + l.w_off, sw, sk, (long long)N * K, (long long)N * K);
+    afr_rtable_add(rt, p->G + l.b_off, sb, sk, N, N);
     return AFR_OK;
 }
-static int run_db(afr_plan* p, hipStream_t s, const void* dy, int Bn, int N, float* Gb) {
-    float* slabs = (float*)(p->ws + p->o_slab_c);
-    const int sp = afr_colsum_splits(Bn);
-    ProfScope ps(p, s, "colsum+reduce", 0.0, (double)p->act_bytes * Bn * N);
-    HIPCHK(afr_launch_colsum(p->cfg.dtype, dy, Bn, N, N, slabs, s));
-    HIPCHK(afr_launch_reduce(Gb, slabs, sp, N, N, 1.f, 0, s));
+static int run_reduce_group(afr_plan* p, hipStream_t s, const RTable& rt) {
+    double bytes = 0;
+    for (int i = 0; i < rt.nseg; ++i) bytes += 16.0 * rt.seg[i].n4 * (rt.seg[i].nslabs + 1);
+    ProfScope ps(p, s, "reduce_group", 0.0, bytes);
+    HIPCHK(afr_launch_reduce_group(rt, s));
     return AFR_OK;
 }
 
@@ -487,12 +487,13 @@ extern "C" int afr_backward(afr_plan* p, void* stream) {
     const int ob = c.dtype == AFR_BF16 ? AFR_GEMM_OUT_BF16 : 0;
     void* du = p->ws + p->o_u;
     int rc;
+    RTable rt;
+    rt.nseg = 0; rt.nblocks = 0;
     if (c.kind == AFR_KIND_SHEET) {
         const int Kz = c.max_length * c.fc_dim;
         void* z = p->ws + p->o_z;
         void* dz = p->ws + p->o_dz;
-        if ((rc = run_dw(p, s, du, z, B, Pix, Kz, p->G + p->s_wout))) return rc;
-        if ((rc = run_db(p, s, du, B, Pix, p->G + p->s_bout))) return rc;
+        if ((rc = run_dw(p, s, p->layers[0], du, z, B, rt))) return rc;
         if ((rc = run_gemm(p, s, AFR_GEMM_B_KSTRIDED | ob, du, weight_ptr(p, p->s_wout), dz, nullptr, nullptr, B, Kz, Pix, Pix,
                            Kz, Kz, 0, 1, 0))) return rc;
         SheetDims d{p->last_L, c.max_length, c.embed_dim, c.heads, c.fc_dim, c.vocab};
@@ -504,8 +505,9 @@ extern "C" int afr_backward(afr_plan* p, void* stream) {
             ProfScope ps(p, s, "sheet_bwd", 0.0, 0.0);
             HIPCHK(afr_launch_sheet_bwd(c.dtype, d, sheet_params(p), make_drop(p, p->last_training, p->last_step), p->last_x,
                                         p->last_ldx, B, dz, c.ln_eps, slabs, so, s));
-            HIPCHK(afr_launch_reduce(p->G, slabs, afr_sheet_blocks(B), (long long)so.total, (long long)so.total, 1.f, 0, s));
         }
+        afr_rtable_add(rt, p->G, slabs, afr_sheet_blocks(B), (long long)so.total, (long long)so.total);
+        if ((rc = run_reduce_group(p, s, rt))) return rc;
     } else {
         const int nl = (int)p->layers.size();
         const void* dy = du;
@@ -513,8 +515,7 @@ extern "C" int afr_backward(afr_plan* p, void* stream) {
         for (int i = nl - 1; i >= 0; --i) {
             const auto& l = p->layers[i];
             const void* a = p->ws + p->o_act[i];
-            if ((rc = run_dw(p, s, dy, a, B, l.N, l.K, p->G + l.w_off))) return rc;
-            if ((rc = run_db(p, s, dy, B, l.N, p->G + l.b_off))) return rc;
+            if ((rc = run_dw(p, s, l, dy, a, B, rt))) return rc;
             void* dx = p->ws + p->o_d[pp];
             const int fl = AFR_GEMM_B_KSTRIDED | ob | (i > 0 ? AFR_GEMM_RELU_MASK : 0);
             if ((rc = run_gemm(p, s, fl, dy, weight_ptr(p, l.w_off), dx, nullptr, i > 0 ? a : nullptr, B, l.K, l.N, l.N, l.K, l.K,
@@ -528,12 +529,12 @@ extern "C" int afr_backward(afr_plan* p, void* stream) {
         {
             ProfScope ps(p, s, "glyph_embed_bwd", 0.0, 0.0);
             HIPCHK(afr_launch_glyph_embed_bwd(c.dtype, dy, p->last_x, p->last_font, B, c.embed_dim, c.vocab, c.n_fonts, slabs, s));
-            const long long stride = rows * c.embed_dim;
-            HIPCHK(afr_launch_reduce(p->G + p->emb_off, slabs, blocks, stride, (long long)c.vocab * c.embed_dim, 1.f, 0, s));
-            if (c.n_fonts > 0)
-                HIPCHK(afr_launch_reduce(p->G + p->font_off, slabs + (size_t)c.vocab * c.embed_dim, blocks, stride,
-                                         (long long)c.n_fonts * c.embed_dim, 1.f, 0, s));
         }
+        const long long stride = rows * c.embed_dim;
+        afr_rtable_add(rt, p->G + p->emb_off, slabs, blocks, stride, (long long)c.vocab * c.embed_dim);
+        if (c.n_fonts > 0)
+            afr_rtable_add(rt, p->G + p->font_off, slabs + (size_t)c.vocab * c.embed_dim, blocks, stride, (long long)c.n_fonts * c.embed_dim);
+        if ((rc = run_reduce_group(p, s, rt))) return rc;
     }
     p->have_du = false;
     return AFR_OK;

@@ -68,18 +68,27 @@ struct GemmParams {
     int flags;            // AFR_GEMM_* bits
     int splitk;           // >=1
     long long slab_stride;  // elements between split-K slabs of C
+    // optional fused bias gradient (A must be k-strided): colsum[z*colsum_stride + m] = sum_k A(m,k) over split z
+    float* colsum = nullptr;
+    long long colsum_stride = 0;
 };
 hipError_t afr_launch_gemm(int dtype, const GemmParams& p, hipStream_t s);
 const char* afr_gemm_kernel_name(int dtype, int flags);
 
 hipError_t afr_launch_reduce(float* dst, const float* slabs, int nslabs, long long slab_stride, long long n,
                              float scale, int accumulate, hipStream_t s);
+// grouped reduction: every gradient tensor that was produced as partial slabs, in ONE launch
+struct RSeg { float* dst; const float* src; long long stride; long long n4; int nslabs; int blk0; int nblk; int pad; };
+struct RTable { int nseg; int nblocks; RSeg seg[24]; };
+void afr_rtable_add(RTable& t, float* dst, const float* src, int nslabs, long long stride, long long n);
+hipError_t afr_launch_reduce_group(const RTable& t, hipStream_t s);
 hipError_t afr_launch_adamw(float* p, const float* g, float* m, float* v, bf16_t* shadow, long long n, float lr,
                             float beta1, float beta2, float eps, float wd, float bc1, float bc2, float grad_scale,
                             hipStream_t s);
 // loss: u (act dtype) [rows][cols] -> du in place or to `du`; per-block partial sums to scratch, then
 // a 1-block finisher adds sum(scratch) to *loss_accum (deterministic order).
 int afr_mse_blocks(long long rows, long long cols);
+// scratch: >= 1028 floats; scratch[1024] (as unsigned) is the arrival counter, zero before the first call
 hipError_t afr_launch_mse_grad(int act_dtype, const void* u, const void* target, int target_dtype, void* du,
                                long long rows, long long cols, long long mean_elems, float* loss_accum,
                                float* scratch, hipStream_t s);

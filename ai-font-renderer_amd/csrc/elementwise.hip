@@ -46,6 +46,40 @@ hipError_t afr_launch_reduce(float* dst, const float* slabs, int nslabs, long lo
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------ grouped reduce
+// One launch sums every slab-produced gradient of a backward pass (split-K dW slabs, fused bias partials, embedding
+// partials) into the flat gradient buffer, each in fixed slab order.  Block -> segment by a scan of <= 24 entries.
+__global__ __launch_bounds__(256) void reduce_group_kernel(RTable t) {
+    int si = 0;
+    for (int k = 1; k < t.nseg; ++k) if ((int)blockIdx.x >= t.seg[k].blk0) si = k;
+    const RSeg sg = t.seg[si];
+    for (long long i = (long long)(blockIdx.x - sg.blk0) * 256 + threadIdx.x; i < sg.n4; i += (long long)sg.nblk * 256) {
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float* src = sg.src + 4 * i;
+#pragma unroll 4
+        for (int s = 0; s < sg.nslabs; ++s) {
+            const float4 v = *reinterpret_cast<const float4*>(src + s * sg.stride);
+            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+        }
+        reinterpret_cast<float4*>(sg.dst)[i] = a;
+    }
+}
+void afr_rtable_add(RTable& t, float* dst, const float* src, int nslabs, long long stride, long long n) {
+    if (n <= 0 || t.nseg >= 24) return;
+    RSeg& sg = t.seg[t.nseg];
+    sg.dst = dst; sg.src = src; sg.stride = stride; sg.n4 = n / 4; sg.nslabs = nslabs; sg.blk0 = t.nblocks;
+    long long nb = (sg.n4 + 255) / 256;
+    if (nb > 1024) nb = 1024;
+    sg.nblk = (int)nb; sg.pad = 0;
+    t.nblocks += (int)nb;
+    t.nseg++;
+}
+hipError_t afr_launch_reduce_group(const RTable& t, hipStream_t s) {
+    if (t.nseg == 0) return hipSuccess;
+    hipLaunchKernelGGL(reduce_group_kernel, dim3(t.nblocks), dim3(256), 0, s, t);
+    return hipGetLastError();
+}
+
 // -------------------------------------------------------------------------------------- AdamW
 // torch.optim.AdamW single-tensor update (reference model.py:273,310), one pass over p,g,m,v:
 //   p *= 1 - lr*wd;  m += (g-m)*(1-b1);  v = b2*v + (1-b2)*g*g;  p -= (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps)
@@ -136,7 +170,8 @@ hipError_t afr_launch_clamp_out(int act_dtype, const void* u, float* y, long lon
 template <typename T, typename TT>
 __global__ __launch_bounds__(256) void mse_grad_kernel(const T* __restrict__ u, const TT* __restrict__ tgt,
                                                        T* __restrict__ du, long long n8, float inv_n,
-                                                       float* __restrict__ partial) {
+                                                       float* __restrict__ partial, unsigned* __restrict__ counter,
+                                                       float* __restrict__ loss_accum) {
     float lsum = 0.f;
     const float g2 = 2.f * inv_n;
     for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n8; i += (long long)gridDim.x * 256) {
@@ -179,23 +214,34 @@ __global__ __launch_bounds__(256) void mse_grad_kernel(const T* __restrict__ u, 
         }
     }
     __shared__ float wsum[4];
+    __shared__ unsigned ticket;
     lsum = wave_sum(lsum);
     if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = lsum;
     __syncthreads();
-    if (threadIdx.x == 0) partial[blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
-}
-__global__ __launch_bounds__(256) void loss_finish_kernel(const float* __restrict__ partial, int nblocks, float inv_n,
-                                                          float* __restrict__ loss_accum) {
-    __shared__ float sh[256];
+    // publish this block's partial, take a ticket; the LAST arriver sums all partials in block order (deterministic)
+    // and adds the mean to *loss_accum.  Hand-off form: sc1 payload store, drained, then an agent-scope ticket; the
+    // reader uses sc1 loads only (cdna_hip_programming.md Guideline 16 R1 -- no release fence, which would flush
+    // every dirty du line of the XCD's L2 per block).
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(partial + blockIdx.x, (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the write-through (sc1) store has landed before the ticket
+        ticket = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (ticket != gridDim.x - 1) return;
+    __shared__ float sh[256];                                 // every load of the partials below is an sc1 (agent) load
     float a = 0.f;
-    for (int i = threadIdx.x; i < nblocks; i += 256) a += partial[i];
+    for (int i = threadIdx.x; i < (int)gridDim.x; i += 256) a += __hip_atomic_load(partial + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     sh[threadIdx.x] = a;
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) {
-        if (threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+        if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
         __syncthreads();
     }
-    if (threadIdx.x == 0) loss_accum[0] += sh[0] * inv_n;
+    if (threadIdx.x == 0) {
+        loss_accum[0] += sh[0] * inv_n;
+        __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm for the next call
+    }
 }
 int afr_mse_blocks(long long rows, long long cols) { return grid_for(rows * cols / 8, 256, 1024); }
 hipError_t afr_launch_mse_grad(int act_dtype, const void* u, const void* target, int target_dtype, void* du,
@@ -207,14 +253,14 @@ hipError_t afr_launch_mse_grad(int act_dtype, const void* u, const void* target,
     const int blocks = afr_mse_blocks(rows, cols);
     const float inv_n = (float)(1.0 / (double)mean_elems);
     dim3 g(blocks), b(256);
-#define MSE(T, TT) hipLaunchKernelGGL((mse_grad_kernel<T, TT>), g, b, 0, s, (const T*)u, (const TT*)target, (T*)du, n / 8, inv_n, scratch)
+    unsigned* counter = reinterpret_cast<unsigned*>(scratch + 1024);
+#define MSE(T, TT) hipLaunchKernelGGL((mse_grad_kernel<T, TT>), g, b, 0, s, (const T*)u, (const TT*)target, (T*)du, n / 8, inv_n, scratch, counter, loss_accum)
     if (act_dtype == AFR_BF16) {
         if (target_dtype == AFR_TARGET_U8) MSE(bf16_t, uint8_t); else MSE(bf16_t, float);
     } else {
         if (target_dtype == AFR_TARGET_U8) MSE(float, uint8_t); else MSE(float, float);
     }
 #undef MSE
-    hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(256), 0, s, scratch, blocks, inv_n, loss_accum);
     return hipGetLastError();
 }
 
@@ -290,7 +336,7 @@ hipError_t afr_launch_glyph_embed(int act_dtype, const float* emb, const float* 
 // embedding_dense_backward (model.py:309): dEmb[x[b]] += d[b].  Deterministic, atomic-free: a block takes 256 glyph
 // rows; thread (slot = tid>>5, c = tid&31) is the ONLY writer of LDS rows v with v%8 == slot, column c, and walks the
 // block's rows in order.  Block partials go to slabs[block][(vocab+n_fonts)*E]; afr_launch_reduce sums them in order.
-constexpr int EMB_BWD_ROWS = 256;
+constexpr int EMB_BWD_ROWS = 64;
 template <typename T>
 __global__ __launch_bounds__(256) void glyph_embed_bwd_kernel(const T* __restrict__ d, const int64_t* __restrict__ x,
                                                               const int64_t* __restrict__ font, int B, int E, int vocab,

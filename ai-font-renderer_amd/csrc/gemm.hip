@@ -11,12 +11,30 @@
 // Two operand types:
 //   f32   v_mfma_f32_32x32x2_f32  : exact f32 (one rounding per product, k-ordered fma chain) -- the parity mode
 //   bf16  v_mfma_f32_16x16x32_bf16: bf16 operands, f32 accumulation -- the throughput mode
-// Tile 128x128 per 256-thread workgroup (4 waves as 2x2, 64x64 per wave), register-staged double-buffered LDS:
-// loads of tile t+1 are issued before the MFMAs on tile t and written to the other buffer after them, one
-// barrier per K-tile.  k-strided operands keep their [k][x] orientation in LDS; the bf16 path reads them
-// with ds_read_b64_tr_b16 (hardware transpose), the f32 path by plain indexing (one f32 per lane per MFMA).
+// Tile 128x128 per 256-thread workgroup (4 waves as 2x2, 64x64 per wave), double-buffered LDS, one barrier per
+// K-tile.  bf16: tiles go global -> LDS by LDS-DMA (buffer_load ... lds: no VGPR staging, no ds_write -- ds_write
+// bandwidth was the measured limiter of the register-staged version), tile t+1 in flight during the MFMAs on t.
+// f32: register-staged (loads issued before the MFMAs, written to the other buffer after them).
+// k-strided operands keep their [k][x] orientation in LDS; the bf16 path reads them with ds_read_b64_tr_b16
+// (hardware transpose), the f32 path by plain indexing (one f32 per lane per MFMA).
 #include "afr_common.h"
 #include "../../include/afr.h"
+
+// Block -> (tile, k-split).  The grid is 1-D; blocks b, b+8, b+16 ... share an XCD (and its 4 MiB L2), so the XCD's
+// blocks are given a CONTIGUOUS range of work ids (bijective remap).  Work ids run over the k-split slowest, then
+// the tile index of the LARGER operand, so that operand's tiles are fetched into one XCD's L2 only and the small
+// operand is the one re-read by all eight (placement changes speed only, never results).
+__device__ __forceinline__ void tile_of_block(const GemmParams& p, int BM, int BN, int& tm, int& tn, int& z) {
+    const int nb = gridDim.x, b = blockIdx.x;
+    const int q = nb >> 3, r = nb & 7, xcd = b & 7, idx = b >> 3;
+    const int v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
+    const int tiles = tiles_m * tiles_n;
+    z = v / tiles;
+    const int t = v - z * tiles;
+    if (p.N > p.M) { tn = t / tiles_m; tm = t - tn * tiles_m; }
+    else { tm = t / tiles_n; tn = t - tm * tiles_n; }
+}
 
 // ------------------------------------------------------------------------------------------- f32
 namespace f32k {
@@ -71,10 +89,9 @@ __global__ __launch_bounds__(256) void gemm_f32(GemmParams p) {
     __shared__ __attribute__((aligned(16))) float smem[2 * TILE];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid >> 1, wn = wid & 1;
-    const int tiles_n = (p.N + BN - 1) / BN;
-    const int tm = blockIdx.x / tiles_n, tn = blockIdx.x % tiles_n;
+    int tm, tn, z;
+    tile_of_block(p, BM, BN, tm, tn, z);
     const int m0 = tm * BM, n0 = tn * BN;
-    const int z = blockIdx.y;
     const int klen = ((p.K + p.splitk - 1) / p.splitk + BK - 1) / BK * BK;
     const int kbeg = z * klen;
     const int kend = min(p.K, kbeg + klen);
@@ -90,6 +107,8 @@ __global__ __launch_bounds__(256) void gemm_f32(GemmParams p) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     float4 ra[4], rb[4];
+    const bool do_cs = (ALAY == 1) && p.colsum != nullptr && tn == 0;   // fused bias gradient: column sums of A tiles
+    float cs = 0.f;
     const int nt = (kend > kbeg) ? (kend - kbeg + BK - 1) / BK : 0;
     if (nt > 0) {
         load_tile<ALAY>(A, p.lda, p.M, m0, kbeg, kend, tid, ra);
@@ -119,6 +138,11 @@ __global__ __launch_bounds__(256) void gemm_f32(GemmParams p) {
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
         }
+        if (ALAY == 1 && do_cs) {
+            const int xx = tid & 127, hf = tid >> 7;
+#pragma unroll
+            for (int kk = 0; kk < BK / 2; ++kk) cs += As[(hf * (BK / 2) + kk) * LDA + xx];
+        }
         if (more) {
             float* Sn = smem + (cur ^ 1) * TILE;
             store_tile<ALAY>(Sn, tid, ra);
@@ -128,6 +152,11 @@ __global__ __launch_bounds__(256) void gemm_f32(GemmParams p) {
         cur ^= 1;
     }
 
+    if (ALAY == 1 && do_cs) {
+        smem[tid] = cs;
+        __syncthreads();
+        if (tid < 128 && m0 + tid < p.M) p.colsum[(size_t)z * p.colsum_stride + m0 + tid] = smem[tid] + smem[tid + 128];
+    }
     // epilogue: D[row = (r&3) + 8*(r>>2) + 4*(lane>>5)][col = lane&31]; rows are m, columns n
     const int flags = p.flags;
     const bool out_bf16 = flags & AFR_GEMM_OUT_BF16;
@@ -162,40 +191,31 @@ constexpr int TILE_BYTES = 128 * 64 * 2;  // one operand tile, either orientatio
 
 __device__ __forceinline__ int fswz(int k) { return (k & 3) | (((k >> 3) & 1) << 2); }
 
+// LDS images (bytes) -- both are written LINEARLY by LDS-DMA (one wave-instruction = 64 lanes x 16 B = 1 KiB of
+// consecutive LDS), so the bank swizzle is applied to the per-lane SOURCE address and again on the read:
+//   LAY 0: [128 x][64 k]  128-B rows; position c' of row r holds global 16-B chunk c' ^ (r&7)   -> conflict-free ds_read_b128
+//   LAY 1: [64 k][128 x]  256-B rows; position c' of row k holds global chunk c' ^ (fswz(k)<<1)  -> conflict-free tr reads
+// stage_tile: this wave's share (4 of the tile's 16 KiB) of one operand tile, global -> LDS with no VGPR staging and
+// no ds_write.  Rows / k beyond the operand get a voffset past the descriptor's range: the hardware returns zeros.
 template <int LAY>
-__device__ __forceinline__ void load_tile(const bf16_t* __restrict__ G, int ld, int X, int x0, int k0, int kend,
-                                          int tid, uint4 (&r)[4]) {
+__device__ __forceinline__ void stage_tile(__amdgpu_buffer_rsrc_t rsrc, char* lds_tile, int ld, int X, int x0, int k0,
+                                           int kend, int wave, int lane) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        int idx = tid + 256 * i;
-        uint4 v = make_uint4(0, 0, 0, 0);
+        const int inst = wave * 4 + i;
+        int gx, gk;
         if (LAY == 0) {
-            int row = idx >> 3, c = idx & 7;
-            int gx = x0 + row, gk = k0 + 8 * c;
-            if (gx < X && gk < kend) v = *reinterpret_cast<const uint4*>(G + (size_t)gx * ld + gk);
+            const int r = inst * 8 + (lane >> 3);
+            const int c = (lane & 7) ^ (r & 7);
+            gx = x0 + r; gk = k0 + 8 * c;
         } else {
-            int kr = idx >> 4, c = idx & 15;
-            int gk = k0 + kr, gx = x0 + 8 * c;
-            if (gk < kend && gx < X) v = *reinterpret_cast<const uint4*>(G + (size_t)gk * ld + gx);
+            const int kr = inst * 4 + (lane >> 4);
+            const int c = (lane & 15) ^ (fswz(kr) << 1);
+            gk = k0 + kr; gx = x0 + 8 * c;
         }
-        r[i] = v;
-    }
-}
-// LDS images (bytes):
-//   LAY 0: [128 x][64 k]  128-B rows, 16-B chunk c stored at chunk (c ^ (row&7))  -> conflict-free ds_read_b128
-//   LAY 1: [64 k][128 x]  256-B rows, 32-B block b stored at block (b ^ fswz(k))   -> conflict-free tr reads
-template <int LAY>
-__device__ __forceinline__ void store_tile(char* S, int tid, const uint4 (&r)[4]) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        int idx = tid + 256 * i;
-        if (LAY == 0) {
-            int row = idx >> 3, c = idx & 7;
-            *reinterpret_cast<uint4*>(S + row * 128 + ((c ^ (row & 7)) << 4)) = r[i];
-        } else {
-            int kr = idx >> 4, c = idx & 15;
-            *reinterpret_cast<uint4*>(S + kr * 256 + ((c ^ (fswz(kr) << 1)) << 4)) = r[i];
-        }
+        unsigned off = (LAY == 0) ? (unsigned)(((size_t)gx * ld + gk) * 2) : (unsigned)(((size_t)gk * ld + gx) * 2);
+        if (gx >= X || gk >= kend) off = 0x80000000u;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(lds_tile + inst * 1024), 16, off, 0, 0, 0);
     }
 }
 // fragment for 16 x-rows starting at xb (multiple of 16), k-step ks (32 k each): lane holds
@@ -222,14 +242,13 @@ __device__ __forceinline__ bf16x8 read_frag(const char* S, int xb, int ks, int l
 }
 
 template <int ALAY, int BLAY>
-__global__ __launch_bounds__(256) void gemm_bf16(GemmParams p) {
+__global__ __launch_bounds__(256, 2) void gemm_bf16(GemmParams p) {
     __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];   // 2 buffers x (A,B) = 64 KiB
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid >> 1, wn = wid & 1;
-    const int tiles_n = (p.N + BN - 1) / BN;
-    const int tm = blockIdx.x / tiles_n, tn = blockIdx.x % tiles_n;
+    int tm, tn, z;
+    tile_of_block(p, BM, BN, tm, tn, z);
     const int m0 = tm * BM, n0 = tn * BN;
-    const int z = blockIdx.y;
     const int klen = ((p.K + p.splitk - 1) / p.splitk + BK - 1) / BK * BK;
     const int kbeg = z * klen;
     const int kend = min(p.K, kbeg + klen);
@@ -242,22 +261,29 @@ __global__ __launch_bounds__(256) void gemm_bf16(GemmParams p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    uint4 ra[4], rb[4];
+    const bool do_cs = (ALAY == 1) && p.colsum != nullptr && tn == 0;   // fused bias gradient: column sums of A tiles
+    float cs = 0.f;
     const int nt = (kend > kbeg) ? (kend - kbeg + BK - 1) / BK : 0;
+    const int wave = __builtin_amdgcn_readfirstlane(wid);
+    const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, 0x7FFFFFFF, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, 0x7FFFFFFF, 0x00020000);
     if (nt > 0) {
-        load_tile<ALAY>(A, p.lda, p.M, m0, kbeg, kend, tid, ra);
-        load_tile<BLAY>(B, p.ldb, p.N, n0, kbeg, kend, tid, rb);
-        store_tile<ALAY>(smem, tid, ra);
-        store_tile<BLAY>(smem + TILE_BYTES, tid, rb);
+        stage_tile<ALAY>(rA, smem, p.lda, p.M, m0, kbeg, kend, wave, lane);
+        stage_tile<BLAY>(rB, smem + TILE_BYTES, p.ldb, p.N, n0, kbeg, kend, wave, lane);
     }
-    __syncthreads();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
     int cur = 0;
     for (int t = 0; t < nt; ++t) {
-        const bool more = (t + 1 < nt);
-        if (more) {
-            load_tile<ALAY>(A, p.lda, p.M, m0, kbeg + (t + 1) * BK, kend, tid, ra);
-            load_tile<BLAY>(B, p.ldb, p.N, n0, kbeg + (t + 1) * BK, kend, tid, rb);
+        // tile t+1 streams into the other buffer (LDS-DMA, in flight during the MFMAs below); every wave finished
+        // reading that buffer before the barrier that ended the previous iteration
+#ifndef AFR_ABLATE_NOLOAD
+        if (t + 1 < nt) {
+            char* Sn = smem + (cur ^ 1) * 2 * TILE_BYTES;
+            stage_tile<ALAY>(rA, Sn, p.lda, p.M, m0, kbeg + (t + 1) * BK, kend, wave, lane);
+            stage_tile<BLAY>(rB, Sn + TILE_BYTES, p.ldb, p.N, n0, kbeg + (t + 1) * BK, kend, wave, lane);
         }
+#endif
         const char* As = smem + cur * 2 * TILE_BYTES;
         const char* Bs = As + TILE_BYTES;
 #pragma unroll
@@ -268,21 +294,36 @@ __global__ __launch_bounds__(256) void gemm_bf16(GemmParams p) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) bfr[j] = read_frag<BLAY>(Bs, wn * 64 + 16 * j, ks, lane);
             // operands swapped on purpose: D'[n][m] so that a lane owns 4 consecutive n of one row m
+#ifndef AFR_ABLATE_NOMFMA
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+#else
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { asm volatile("" ::"v"(af[i])); asm volatile("" ::"v"(bfr[i])); }
+#endif
         }
-        if (more) {
-            char* Sn = smem + (cur ^ 1) * 2 * TILE_BYTES;
-            store_tile<ALAY>(Sn, tid, ra);
-            store_tile<BLAY>(Sn + TILE_BYTES, tid, rb);
+        if (ALAY == 1 && do_cs) {
+            const int xx = tid & 127, hf = tid >> 7;
+#pragma unroll 8
+            for (int kk = 0; kk < BK / 2; ++kk) {
+                const int k = hf * (BK / 2) + kk;
+                cs += (float)*reinterpret_cast<const bf16_t*>(As + k * 256 + (((xx >> 4) ^ fswz(k)) << 5) + (xx & 15) * 2);
+            }
         }
-        __syncthreads();
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // the DMA of tile t+1 has landed; my reads of tile t are done
+        __builtin_amdgcn_s_barrier();
         cur ^= 1;
     }
 
+    if (ALAY == 1 && do_cs) {
+        float* red = reinterpret_cast<float*>(smem);
+        red[tid] = cs;
+        __syncthreads();
+        if (tid < 128 && m0 + tid < p.M) p.colsum[(size_t)z * p.colsum_stride + m0 + tid] = red[tid] + red[tid + 128];
+    }
     // epilogue: acc[i][j][r] = C[m = m0 + wm*64 + 16i + (lane&15)][n = n0 + wn*64 + 16j + 4*(lane>>4) + r]
     const int flags = p.flags;
     const bool out_bf16 = flags & AFR_GEMM_OUT_BF16;
@@ -334,7 +375,7 @@ const char* afr_gemm_kernel_name(int dtype, int flags) {
 hipError_t afr_launch_gemm(int dtype, const GemmParams& p, hipStream_t s) {
     const int a = (p.flags & AFR_GEMM_A_KSTRIDED) ? 1 : 0, b = (p.flags & AFR_GEMM_B_KSTRIDED) ? 1 : 0;
     const int tiles = ((p.M + 127) / 128) * ((p.N + 127) / 128);
-    dim3 grid(tiles, p.splitk, 1), block(256, 1, 1);
+    dim3 grid(tiles * p.splitk, 1, 1), block(256, 1, 1);
     if (tiles <= 0) return hipSuccess;
 #define LAUNCH(NS, KRN, AL, BL) hipLaunchKernelGGL((NS::KRN<AL, BL>), grid, block, 0, s, p)
     if (dtype == AFR_BF16) {

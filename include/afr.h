@@ -154,6 +154,7 @@ int afr_op_reduce(float* dst, const float* slabs, int nslabs, int64_t slab_strid
 int afr_op_adamw(float* p, const float* g, float* m, float* v, void* shadow_bf16, int64_t n, float lr,
                  float beta1, float beta2, float eps, float weight_decay, int64_t t, float grad_scale,
                  void* stream);
+/* scratch: >= 1040 floats, zero before the first call (holds per-block partials and the arrival counter) */
 int afr_op_mse_grad(int act_dtype, const void* u, const void* target, int target_dtype, void* du,
                     int64_t rows, int64_t cols, int64_t mean_elems, float* loss_accum, float* scratch,
                     void* stream);

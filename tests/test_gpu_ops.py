@@ -95,7 +95,7 @@ def test_mse_grad_matches_oracle(act, tgt):
     loss_ref, du_ref = oracle.mse_loss_grad(uref.double(), tf.double(), total_elems=rows * cols * 3)
     td = dev(torch.from_numpy(tu8)) if tgt == "u8" else dev(tf)
     loss = torch.zeros(1, device="cuda")
-    scratch = torch.zeros(1024, device="cuda")
+    scratch = torch.zeros(1040, device="cuda")
     du = torch.empty_like(ud)
     _lib.check(_lib.lib().afr_op_mse_grad(_lib.AFR_F32 if act == "f32" else _lib.AFR_BF16, ptr(ud), ptr(td),
                                           _lib.AFR_TARGET_U8 if tgt == "u8" else _lib.AFR_TARGET_F32, ptr(du), rows, cols,
