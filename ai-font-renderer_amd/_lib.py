@@ -45,6 +45,7 @@ SIGNATURES = {
     "afr_sync_params": (_i32, [_vp, _vp]),
     "afr_forward": (_i32, [_vp, _vp, _vp, _i32, _i32, _vp, _i32, _u64, _vp]),
     "afr_loss_grad": (_i32, [_vp, _vp, _i32, _i32, _i64, _vp, _vp]),
+    "afr_set_output_grad": (_i32, [_vp, _vp, _i32, _vp]),
     "afr_backward": (_i32, [_vp, _vp]),
     "afr_adamw_step": (_i32, [_vp, _f32, _f32, _f32, _f32, _f32, _i64, _f32, _vp]),
     "afr_train_step": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i64, _vp, _u64, _i32, _f32, _f32, _f32, _f32, _f32, _i64, _vp]),

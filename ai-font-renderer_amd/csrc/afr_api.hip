@@ -477,6 +477,15 @@ extern "C" int afr_loss_grad(afr_plan* p, const void* target, int tdtype, int B,
     return AFR_OK;
 }
 
+extern "C" int afr_set_output_grad(afr_plan* p, const float* dy, int B, void* stream) {
+    if (!p || !p->P) return fail(AFR_ESTATE, "plan has no bound parameters");
+    if (!dy) return fail(AFR_EINVAL, "dy is null");
+    if (B != p->last_B) return fail(AFR_ESTATE, "batch %d does not match the last forward (%d)", B, p->last_B);
+    HIPCHK(afr_launch_clamp_bwd(p->cfg.dtype, p->ws + p->o_u, dy, (long long)B * p->cfg.out_h * p->cfg.out_w, (hipStream_t)stream));
+    p->have_du = true;
+    return AFR_OK;
+}
+
 // ------------------------------------------------------------------------------------ backward
 extern "C" int afr_backward(afr_plan* p, void* stream) {
     if (!p || !p->P || !p->G) return fail(AFR_ESTATE, "plan has no bound parameter/gradient buffers");
@@ -570,6 +579,7 @@ extern "C" int afr_error_flags(afr_plan* p, void* stream, uint32_t* out) {
     hipStream_t s = (hipStream_t)stream;
     HIPCHK(hipMemcpyAsync(out, p->ws + p->o_err, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
+    if (*out) HIPCHK(hipMemsetAsync(p->ws + p->o_err, 0, sizeof(uint32_t), s));   // read-and-clear
     return AFR_OK;
 }
 

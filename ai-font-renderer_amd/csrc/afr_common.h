@@ -93,6 +93,7 @@ hipError_t afr_launch_mse_grad(int act_dtype, const void* u, const void* target,
                                long long rows, long long cols, long long mean_elems, float* loss_accum,
                                float* scratch, hipStream_t s);
 hipError_t afr_launch_f32_to_bf16(const float* src, bf16_t* dst, long long n, hipStream_t s);
+hipError_t afr_launch_clamp_bwd(int act_dtype, void* u_inout, const float* dy, long long n, hipStream_t s);
 hipError_t afr_launch_clamp_out(int act_dtype, const void* u, float* y, long long n, hipStream_t s);
 // column sums of X[rows][cols] (act dtype) -> slabs[nsplit][cols] (f32); returns nsplit via out param
 int afr_colsum_splits(long long rows);

@@ -162,6 +162,21 @@ hipError_t afr_launch_clamp_out(int act_dtype, const void* u, float* y, long lon
     return hipGetLastError();
 }
 
+// du = dy * [0 <= u <= 1], in place over u: torch.clamp's backward (reference model.py:156) for a caller-side loss
+template <typename T>
+__global__ __launch_bounds__(256) void clamp_bwd_kernel(T* __restrict__ u, const float* __restrict__ dy, long long n) {
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const float uv = (float)u[i];
+        u[i] = (T)((uv >= 0.f && uv <= 1.f) ? dy[i] : 0.f);
+    }
+}
+hipError_t afr_launch_clamp_bwd(int act_dtype, void* u, const float* dy, long long n, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    if (act_dtype == AFR_BF16) hipLaunchKernelGGL(clamp_bwd_kernel<bf16_t>, dim3(grid_for(n, 256)), dim3(256), 0, s, (bf16_t*)u, dy, n);
+    else hipLaunchKernelGGL(clamp_bwd_kernel<float>, dim3(grid_for(n, 256)), dim3(256), 0, s, (float*)u, dy, n);
+    return hipGetLastError();
+}
+
 // ------------------------------------------------------------------------- MSE loss + gradient
 // loss = sum((clamp(u,0,1) - t)^2) / mean_elems ;  du = 2 (y - t) / mean_elems * [0 <= u <= 1]
 // (reference model.py:156,268-270 and the first step of loss.backward(), model.py:309).

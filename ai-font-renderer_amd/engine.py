@@ -57,10 +57,10 @@ class Engine:
             raise RuntimeError("ai_font_renderer_amd.Engine needs an MI355X: the hot path has no CPU fallback")
         self.lib = _lib.lib()
         self.cfg, self.dtype, self.max_batch = cfg, dtype, int(max_batch)
+        self.seed, self.rank = int(seed), int(rank)
         self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
-        self._c = make_afr_config(cfg, dtype, max_batch, seed, rank)
-        self._plan = C.c_void_p()
-        _lib.check(self.lib.afr_plan_create(C.byref(self._c), C.byref(self._plan)))
+        self._plan = None
+        self._make_plan(self.max_batch)
         n = self.lib.afr_param_elems(self._plan)
         self.n_flat = int(n)
         with torch.cuda.device(self.device):
@@ -68,11 +68,8 @@ class Engine:
             self.flat_grads = torch.zeros(n, dtype=torch.float32, device=self.device)
             self.exp_avg = torch.zeros(n, dtype=torch.float32, device=self.device) if with_optimizer else None
             self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=self.device) if with_optimizer else None
-            self.ws_bytes = int(self.lib.afr_workspace_bytes(self._plan))
-            self.workspace = torch.zeros(self.ws_bytes, dtype=torch.uint8, device=self.device)
             self.loss_accum = torch.zeros(1, dtype=torch.float32, device=self.device)
-        _lib.check(self.lib.afr_bind(self._plan, _ptr(self.flat_params), _ptr(self.flat_grads), _ptr(self.exp_avg),
-                                     _ptr(self.exp_avg_sq), _ptr(self.workspace), self.ws_bytes))
+        self._bind()
         self.layout = []
         name = C.create_string_buffer(128)
         off, numel, ndim = C.c_int64(), C.c_int64(), C.c_int32()
@@ -85,6 +82,29 @@ class Engine:
         self.pixels = cfg.pixels
         self.t = 0            # AdamW step counter (model.py:310)
         self._keep = None     # keeps the last inputs alive until backward has consumed them
+
+    def _make_plan(self, max_batch):
+        if self._plan:
+            self.lib.afr_plan_destroy(self._plan)
+        self.max_batch = int(max_batch)
+        self._c = make_afr_config(self.cfg, self.dtype, self.max_batch, self.seed, self.rank)
+        self._plan = C.c_void_p()
+        _lib.check(self.lib.afr_plan_create(C.byref(self._c), C.byref(self._plan)))
+
+    def _bind(self):
+        with torch.cuda.device(self.device):
+            self.ws_bytes = int(self.lib.afr_workspace_bytes(self._plan))
+            self.workspace = torch.zeros(self.ws_bytes, dtype=torch.uint8, device=self.device)
+        _lib.check(self.lib.afr_bind(self._plan, _ptr(self.flat_params), _ptr(self.flat_grads), _ptr(self.exp_avg),
+                                     _ptr(self.exp_avg_sq), _ptr(self.workspace), self.ws_bytes))
+
+    def ensure_batch(self, B):
+        """Grow the plan's workspace for a larger batch; parameters, gradients and moments stay where they are."""
+        if B > self.max_batch:
+            torch.cuda.synchronize(self.device)
+            self._make_plan(B)
+            self._bind()
+            self.sync_params()
 
     def __del__(self):
         try:
@@ -125,6 +145,7 @@ class Engine:
 
     def forward(self, x, font=None, training=False, step=0, want_output=True):
         x, font = self._prep_x(x, font)
+        self.ensure_batch(x.shape[0])
         if isinstance(self.cfg, SheetConfig):
             if x.dim() != 2:
                 raise ValueError("sheet model takes int64 [B, L] codes")
@@ -152,6 +173,12 @@ class Engine:
         _lib.check(self.lib.afr_loss_grad(self._plan, _ptr(t), td, B, me, _ptr(self.loss_accum), _stream()))
         self._keep_t = t
 
+    def set_output_grad(self, dy):
+        """dy = d(loss)/d(clamped output) from a caller-side loss (autograd); float32 [B, pixels]."""
+        dy = dy.to(self.device, dtype=torch.float32).contiguous()
+        _lib.check(self.lib.afr_set_output_grad(self._plan, _ptr(dy), dy.shape[0], _stream()))
+        self._keep_t = dy
+
     def backward(self):
         _lib.check(self.lib.afr_backward(self._plan, _stream()))
 
@@ -163,6 +190,7 @@ class Engine:
                    mean_elems=None, do_step=True):
         """zero_grad -> forward -> loss -> backward -> AdamW, one C call (model.py:292-310)."""
         x, font = self._prep_x(x, font)
+        self.ensure_batch(x.shape[0])
         t, td = self._target(target)
         if isinstance(self.cfg, SheetConfig):
             B, L = x.shape

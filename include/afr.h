@@ -101,6 +101,10 @@ int afr_forward(afr_plan* plan, const int64_t* x, const int64_t* font, int B, in
 int afr_loss_grad(afr_plan* plan, const void* target, int target_dtype, int B, int64_t mean_elems,
                   float* loss_accum, void* stream);
 
+/* Entry for a caller-owned loss (torch.autograd): dy = d(loss)/d(y) for the clamped output y [B, pixels], float32.
+ * Applies the clamp's gradient mask (0 <= u <= 1, inclusive) and leaves du where afr_backward expects it. */
+int afr_set_output_grad(afr_plan* plan, const float* dy, int B, void* stream);
+
 /* loss.backward(): model.py:309.  Overwrites the flat gradient buffer (zero_grad, model.py:292,
  * is implied). */
 int afr_backward(afr_plan* plan, void* stream);
@@ -118,7 +122,7 @@ int afr_train_step(afr_plan* plan, const int64_t* x, const int64_t* font, const 
                    float weight_decay, int64_t t, void* stream);
 
 /* Set / read the device-side error word (bit 0: an embedding index outside [0,vocab), the
- * condition on which the reference raises IndexError; model.py:136,167).  Reading synchronises. */
+ * condition on which the reference raises IndexError; model.py:136,167).  Reading synchronises and clears. */
 int afr_error_flags(afr_plan* plan, void* stream, uint32_t* flags_out);
 
 /* Name and average duration (ms, hipEvent-timed on the launch stream) of the plan's dominant

@@ -1,0 +1,145 @@
+"""GPU: the drop-in Python surface (ai_font_renderer_amd.model / .helpers) on top of the HIP engine."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from .util import MINI, load, maxabs, oracle, synth
+
+pytestmark = pytest.mark.gpu
+
+KEYS = ["positional_encoding", "embedding.weight", "attention.in_proj_weight", "attention.in_proj_bias",
+        "attention.out_proj.weight", "attention.out_proj.bias", "layer_norm.weight", "layer_norm.bias",
+        "fc1.weight", "fc1.bias", "fc_output.weight", "fc_output.bias"]
+
+
+@pytest.fixture
+def mini_module(monkeypatch):
+    from ai_font_renderer_amd import model as M
+    monkeypatch.setattr(M, "SHEET_HEIGHT", 8)
+    monkeypatch.setattr(M, "SHEET_WIDTH", 24)
+    return M
+
+
+def test_module_state_dict_is_the_reference_checkpoint_contract(mini_module, tmp_path):
+    M = mini_module
+    m = M.AttentionFontRenderer(max_length=10)
+    sd = m.state_dict()
+    assert list(sd.keys()) == KEYS                                        # order and names, SURVEY.md 8a
+    assert sd["fc_output.weight"].shape == (192, 640) and sd["attention.in_proj_bias"].shape == (96,)
+    assert len(list(m.parameters())) == 12 and m.max_length == 10 and m.embedding_dim == 32
+    # same-seed default init == torch's own layer constructors in the reference's creation order
+    torch.manual_seed(123)
+    a = M.AttentionFontRenderer(max_length=10).state_dict()
+    torch.manual_seed(123)
+    ref = M._reference_style_init(M.AttentionFontRenderer(max_length=10, init=False).config)
+    for k in KEYS:
+        assert torch.equal(a[k].cpu(), ref[k]), k
+    # save / load round trip through helpers (plain torch state_dict file)
+    from ai_font_renderer_amd import helpers
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_params(MINI).items()})
+    helpers.save_model(m, str(tmp_path / "w.pth"))
+    m2 = helpers.load_model(M.AttentionFontRenderer, 10, filename=str(tmp_path / "w.pth"), device=M.device)
+    assert not m2.training
+    fx = load("sheet_mini.npz")
+    y = m2(torch.from_numpy(fx["x14"]))
+    assert maxabs(y.cpu().numpy(), fx["eval_y14"]) < 2e-5                 # reference output, truncate branch
+    with pytest.raises(IndexError):
+        m2(torch.full((1, 10), 130, dtype=torch.int64))
+    assert maxabs(m2(torch.from_numpy(fx["x6"])).cpu().numpy(), fx["eval_y6"]) < 2e-5   # flag was cleared
+
+
+def test_autograd_path_matches_reference_gradients(mini_module):
+    """User-style loop: outputs = model(x); loss = mse_loss(outputs, t); loss.backward() (model.py:299-309)."""
+    M = mini_module
+    fx = load("sheet_mini.npz")
+    from dataclasses import replace
+    from ai_font_renderer_amd.engine import Engine
+    m = M.AttentionFontRenderer(max_length=10, init=False)
+    # the golden was captured with the three dropouts off: swap in an engine with zero rates and re-point parameters
+    m.engine = Engine(replace(m.config, p_embed=0.0, p_attn=0.0, p_fc=0.0), dtype="f32", max_batch=8, device=M.device)
+    m.engine.load_params(synth.make_params(MINI))
+    P = {k: torch.nn.Parameter(v) for k, v in m.engine.params.items()}
+    for name in KEYS:
+        mod_, _, attr = name.rpartition(".")
+        (m.get_submodule(mod_) if mod_ else m)._parameters[attr] = P[name]
+    m.train()
+    x = torch.from_numpy(fx["x10"])
+    t = torch.from_numpy(fx["target_u8"].astype(np.float32) / 255.0).to(M.device)
+    out = m(x)
+    assert out.requires_grad
+    loss = F.mse_loss(out, t.view(out.shape))
+    loss.backward()
+    assert abs(float(loss.detach()) - float(fx["nodrop_loss"])) < 2e-6
+    for k, p in m.named_parameters():
+        ref = fx["nodrop_grad/" + k]
+        assert maxabs(p.grad.cpu().numpy(), ref) / max(1e-7, np.abs(ref).max()) < 1e-4, k
+    # a stock torch optimiser can drive the parameters through those .grad views
+    before = m.state_dict()["fc1.bias"].clone()
+    torch.optim.SGD(m.parameters(), lr=0.1).step()
+    assert not torch.equal(before, m.state_dict()["fc1.bias"])
+
+
+def test_render_strings_writes_the_reference_bitmaps(tmp_path):
+    """15 test_strings -> string_{i}.bmp: 8-bit BMPs whose pixels are the reference's (a*255).astype(uint8) +-1."""
+    from PIL import Image
+    from ai_font_renderer_amd import helpers, model as M
+    fx = load("sheet_r0.npz")
+    m = M.AttentionFontRenderer(max_length=100, max_batch=16, init=False)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_params(M.AttentionFontRenderer(max_length=100, max_batch=1, init=False).config).items()})
+    helpers.render_strings(m, M.test_strings, str(tmp_path / "out"), 80, 240, M.device)
+    want = oracle.sheet_to_u8(fx["test_eval_y"])
+    for i in range(15):
+        img = Image.open(tmp_path / "out" / f"string_{i}.bmp")
+        assert img.mode == "L" and img.size == (240, 80)
+        got = np.array(img)
+        assert np.abs(got.astype(int) - want[i].astype(int)).max() <= 1
+        assert (got != want[i]).mean() < 1e-3
+
+
+def test_train_string_renderer_end_to_end(tmp_path, monkeypatch):
+    """`python model.py --train` in miniature: 96 generated sheets, 7 epochs, every artefact of the reference run."""
+    from ai_font_renderer_amd import datagen, model as M
+    monkeypatch.chdir(tmp_path)
+    datagen.generate("train_input", 96)
+    monkeypatch.setattr(M, "NUM_SAMPLES", 96)
+    monkeypatch.setattr(M, "NUM_EPOCHS", 7)
+    monkeypatch.setattr(M, "OUTPUT_DIR", "train_output_test")
+    torch.manual_seed(42)
+    with pytest.raises(SystemExit) as e:
+        M.main(["model.py", "--nope"])
+    assert e.value.code == 1
+    M.main(["model.py", "--train"])
+    out = tmp_path / "train_output_test"
+    cfg = (out / "config.txt").read_text().splitlines()
+    assert cfg[0] == "# Training configuration" and "batch_size = 1024" in cfg and "data_size = 96" in cfg
+    res = dict(l.split(" = ") for l in (out / "training_results.txt").read_text().splitlines()[1:])
+    assert res["final_epoch"] == "7" and res["early_stopped"] == "False" and res["training_duration_epochs"] == "7"
+    assert res["final_learning_rate"] == "0.001000"
+    for ep in (0, 5):
+        assert sorted(os.listdir(out / f"epoch_{ep}")) == sorted(f"string_{i}.bmp" for i in range(15))
+    assert (out / "string_14.bmp").exists() and (tmp_path / "font_renderer.pth").exists()
+    sd = torch.load(tmp_path / "font_renderer.pth", weights_only=True)
+    assert list(sd.keys()) == KEYS
+    assert float(res["best_validation_loss"]) < 0.5
+    # render-only mode picks the checkpoint up
+    monkeypatch.setattr(M, "OUTPUT_DIR", "render_only")
+    M.main(["model.py"])
+    assert (tmp_path / "render_only" / "string_0.bmp").exists()
+
+
+def test_training_reduces_the_loss_on_a_fixed_batch():
+    from ai_font_renderer_amd.engine import Engine
+    from .util import SheetConfig
+    cfg = SheetConfig(max_length=24, sheet_h=16, sheet_w=40)
+    eng = Engine(cfg, max_batch=64)
+    eng.load_params(synth.make_params(cfg))
+    x = torch.from_numpy(synth.encode_strings(synth.dataset_strings(64), 24))
+    t = torch.from_numpy(synth.synth_sheet_targets(64, 16, 40, tensor_id=960))
+    losses = []
+    for _ in range(40):
+        eng.train_step(x, t)
+        losses.append(eng.read_loss())
+    assert losses[-1] < 0.6 * losses[0]
