@@ -186,39 +186,50 @@ __global__ __launch_bounds__(256) void gemm_f32(GemmParams p) {
 
 // ------------------------------------------------------------------------------------------ bf16
 namespace bf16k {
-constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int TILE_BYTES = 128 * 64 * 2;  // one operand tile, either orientation
+constexpr int BN = 128, BK = 64;
+constexpr int SUB = 128 * 64 * 2;   // 16 KiB: one 128-wide operand sub-tile (either orientation)
 
 __device__ __forceinline__ int fswz(int k) { return (k & 3) | (((k >> 3) & 1) << 2); }
 
-// LDS images (bytes) -- both are written LINEARLY by LDS-DMA (one wave-instruction = 64 lanes x 16 B = 1 KiB of
+// LDS sub-tile images (bytes) -- written LINEARLY by LDS-DMA (one wave-instruction = 64 lanes x 16 B = 1 KiB of
 // consecutive LDS), so the bank swizzle is applied to the per-lane SOURCE address and again on the read:
 //   LAY 0: [128 x][64 k]  128-B rows; position c' of row r holds global 16-B chunk c' ^ (r&7)   -> conflict-free ds_read_b128
 //   LAY 1: [64 k][128 x]  256-B rows; position c' of row k holds global chunk c' ^ (fswz(k)<<1)  -> conflict-free tr reads
-// stage_tile: this wave's share (4 of the tile's 16 KiB) of one operand tile, global -> LDS with no VGPR staging and
-// no ds_write.  Rows / k beyond the operand get a voffset past the descriptor's range: the hardware returns zeros.
-template <int LAY>
-__device__ __forceinline__ void stage_tile(__amdgpu_buffer_rsrc_t rsrc, char* lds_tile, int ld, int X, int x0, int k0,
-                                           int kend, int wave, int lane) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int inst = wave * 4 + i;
-        int gx, gk;
-        if (LAY == 0) {
-            const int r = inst * 8 + (lane >> 3);
-            const int c = (lane & 7) ^ (r & 7);
-            gx = x0 + r; gk = k0 + 8 * c;
-        } else {
-            const int kr = inst * 4 + (lane >> 4);
-            const int c = (lane & 15) ^ (fswz(kr) << 1);
-            gk = k0 + kr; gx = x0 + 8 * c;
-        }
-        unsigned off = (LAY == 0) ? (unsigned)(((size_t)gx * ld + gk) * 2) : (unsigned)(((size_t)gk * ld + gx) * 2);
-        if (gx >= X || gk >= kend) off = 0x80000000u;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(lds_tile + inst * 1024), 16, off, 0, 0, 0);
-    }
+// stage_inst: wave-instruction `inst` (0..15) of one sub-tile, global -> LDS with no VGPR staging and no ds_write.
+// Rows / k beyond the operand get a voffset past the descriptor's range: the hardware returns zeros.
+// The DMA is issued from inline asm on purpose: when hipcc sees a pending LDS-DMA it puts `s_waitcnt vmcnt(0)` in
+// front of the next ds_read_b64_tr_b16 / plain LDS load (measured: the whole 3-stage ring drained every K-step on the
+// k-strided orientations).  Hidden from the compiler, the only waits are the counted ones placed by hand below.
+// M0 (the LDS destination base) is compiler-reserved: saved and restored inside the same statement.
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+__device__ __forceinline__ void dma16(i32x4 rsrc, unsigned lds_addr, unsigned voff) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(lds_addr), "s"(rsrc) : "memory");
 }
-// fragment for 16 x-rows starting at xb (multiple of 16), k-step ks (32 k each): lane holds
+__device__ __forceinline__ i32x4 make_rsrc(const void* base) {
+    const unsigned long long a = (unsigned long long)base;
+    i32x4 r = {(int)(unsigned)a, (int)((unsigned)(a >> 32) & 0xFFFFu), 0x7FFFFFFF, 0x00020000};
+    return r;
+}
+template <int LAY>
+__device__ __forceinline__ void stage_inst(i32x4 rsrc, unsigned lds_sub, int ld, int X, int x0, int k0,
+                                           int kend, int inst, int lane) {
+    int gx, gk;
+    if (LAY == 0) {
+        const int r = inst * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ (r & 7);
+        gx = x0 + r; gk = k0 + 8 * c;
+    } else {
+        const int kr = inst * 4 + (lane >> 4);
+        const int c = (lane & 15) ^ (fswz(kr) << 1);
+        gk = k0 + kr; gx = x0 + 8 * c;
+    }
+    unsigned off = (LAY == 0) ? (unsigned)(((size_t)gx * ld + gk) * 2) : (unsigned)(((size_t)gk * ld + gx) * 2);
+    if (gx >= X || gk >= kend) off = 0x80000000u;
+    dma16(rsrc, lds_sub + inst * 1024, off);
+}
+// fragment for 16 x-rows starting at xb (multiple of 16, within the sub-tile), k-step ks (32 k each): lane holds
 // X(x = xb + (lane&15), k = 32*ks + 8*(lane>>4) + j), j = 0..7
 template <int LAY>
 __device__ __forceinline__ bf16x8 read_frag(const char* S, int xb, int ks, int lane) {
@@ -241,11 +252,21 @@ __device__ __forceinline__ bf16x8 read_frag(const char* S, int xb, int ks, int l
     }
 }
 
-template <int ALAY, int BLAY>
-__global__ __launch_bounds__(256, 2) void gemm_bf16(GemmParams p) {
-    __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];   // 2 buffers x (A,B) = 64 KiB
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int wm = wid >> 1, wn = wid & 1;
+// WM = waves along M: tile (64*WM) x 128, 2*WM waves of 64x64.
+//   WM=2: 128x128, 256 threads, 2 LDS stages (64 KiB) -> 2 blocks/CU; for small grids.
+//   WM=4: 256x128, 512 threads, 3-stage LDS ring (144 KiB), tile t+2 in flight behind a COUNTED vmcnt and a raw
+//         s_barrier: the main loop was latency-bound on global->LDS with one tile in flight, and the bigger tile
+//         needs 25 % fewer DMA bytes per FLOP.
+template <int ALAY, int BLAY, int WM>
+__global__ __launch_bounds__(128 * WM, 2) void gemm_bf16(GemmParams p) {
+    constexpr int BM = 64 * WM, NW = 2 * WM, NTHR = 64 * NW, ASUB = WM / 2;
+    constexpr int STAGES = (WM == 4) ? 3 : 2;
+    constexpr int STAGE_BYTES = (ASUB + 1) * SUB;
+    constexpr int A_PER_WAVE = ASUB * 16 / NW, B_PER_WAVE = 16 / NW;
+    __shared__ __attribute__((aligned(16))) char smem[STAGES * STAGE_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
     int tm, tn, z;
     tile_of_block(p, BM, BN, tm, tn, z);
     const int m0 = tm * BM, n0 = tn * BN;
@@ -264,33 +285,42 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16(GemmParams p) {
     const bool do_cs = (ALAY == 1) && p.colsum != nullptr && tn == 0;   // fused bias gradient: column sums of A tiles
     float cs = 0.f;
     const int nt = (kend > kbeg) ? (kend - kbeg + BK - 1) / BK : 0;
-    const int wave = __builtin_amdgcn_readfirstlane(wid);
-    const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, 0x7FFFFFFF, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)B, 0, 0x7FFFFFFF, 0x00020000);
-    if (nt > 0) {
-        stage_tile<ALAY>(rA, smem, p.lda, p.M, m0, kbeg, kend, wave, lane);
-        stage_tile<BLAY>(rB, smem + TILE_BYTES, p.ldb, p.N, n0, kbeg, kend, wave, lane);
-    }
+    const i32x4 rA = make_rsrc(A), rB = make_rsrc(B);
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+
+    auto stage = [&](int t, int slot) {
+        const unsigned S = lds0 + slot * STAGE_BYTES;
+        const int k0 = kbeg + t * BK;
+#pragma unroll
+        for (int i = 0; i < A_PER_WAVE; ++i) {
+            const int g = wave * A_PER_WAVE + i;
+            const int sub = g >> 4;
+            stage_inst<ALAY>(rA, S + sub * SUB, p.lda, p.M, m0 + sub * 128, k0, kend, g & 15, lane);
+        }
+#pragma unroll
+        for (int i = 0; i < B_PER_WAVE; ++i)
+            stage_inst<BLAY>(rB, S + ASUB * SUB, p.ldb, p.N, n0, k0, kend, wave * B_PER_WAVE + i, lane);
+    };
+
+#pragma unroll
+    for (int t = 0; t < STAGES - 1; ++t)
+        if (t < nt) stage(t, t);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    int cur = 0;
+    int slot = 0;
     for (int t = 0; t < nt; ++t) {
-        // tile t+1 streams into the other buffer (LDS-DMA, in flight during the MFMAs below); every wave finished
-        // reading that buffer before the barrier that ended the previous iteration
+        // tile t+STAGES-1 streams into the slot whose tile every wave finished reading before the last barrier
 #ifndef AFR_ABLATE_NOLOAD
-        if (t + 1 < nt) {
-            char* Sn = smem + (cur ^ 1) * 2 * TILE_BYTES;
-            stage_tile<ALAY>(rA, Sn, p.lda, p.M, m0, kbeg + (t + 1) * BK, kend, wave, lane);
-            stage_tile<BLAY>(rB, Sn + TILE_BYTES, p.ldb, p.N, n0, kbeg + (t + 1) * BK, kend, wave, lane);
-        }
+        if (t + STAGES - 1 < nt) { int sl = slot + STAGES - 1; if (sl >= STAGES) sl -= STAGES; stage(t + STAGES - 1, sl); }
 #endif
-        const char* As = smem + cur * 2 * TILE_BYTES;
-        const char* Bs = As + TILE_BYTES;
+        const char* S = smem + slot * STAGE_BYTES;
+        const char* As = S + (wm >> 1) * SUB;
+        const char* Bs = S + ASUB * SUB;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             bf16x8 af[4], bfr[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) af[i] = read_frag<ALAY>(As, wm * 64 + 16 * i, ks, lane);
+            for (int i = 0; i < 4; ++i) af[i] = read_frag<ALAY>(As, (wm & 1) * 64 + 16 * i, ks, lane);
 #pragma unroll
             for (int j = 0; j < 4; ++j) bfr[j] = read_frag<BLAY>(Bs, wn * 64 + 16 * j, ks, lane);
             // operands swapped on purpose: D'[n][m] so that a lane owns 4 consecutive n of one row m
@@ -306,23 +336,32 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16(GemmParams p) {
 #endif
         }
         if (ALAY == 1 && do_cs) {
-            const int xx = tid & 127, hf = tid >> 7;
+            const int xx = tid % BM, hf = tid / BM;
+            const char* Ac = S + (xx >> 7) * SUB;
+            const int xl = xx & 127;
 #pragma unroll 8
             for (int kk = 0; kk < BK / 2; ++kk) {
                 const int k = hf * (BK / 2) + kk;
-                cs += (float)*reinterpret_cast<const bf16_t*>(As + k * 256 + (((xx >> 4) ^ fswz(k)) << 5) + (xx & 15) * 2);
+                cs += (float)*reinterpret_cast<const bf16_t*>(Ac + k * 256 + (((xl >> 4) ^ fswz(k)) << 5) + (xl & 15) * 2);
             }
         }
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // the DMA of tile t+1 has landed; my reads of tile t are done
+        // tile t+1 must have landed; with a 3-stage ring the DMA of tile t+2 (the newest A_PER_WAVE+B_PER_WAVE
+        // wave-instructions) stays in flight across the barrier
+        if (STAGES == 3 && t + 2 < nt) {
+            if (A_PER_WAVE + B_PER_WAVE == 6) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        }
         __builtin_amdgcn_s_barrier();
-        cur ^= 1;
+        if (++slot == STAGES) slot = 0;
     }
 
     if (ALAY == 1 && do_cs) {
         float* red = reinterpret_cast<float*>(smem);
         red[tid] = cs;
         __syncthreads();
-        if (tid < 128 && m0 + tid < p.M) p.colsum[(size_t)z * p.colsum_stride + m0 + tid] = red[tid] + red[tid + 128];
+        if (tid < BM && m0 + tid < p.M) p.colsum[(size_t)z * p.colsum_stride + m0 + tid] = red[tid] + red[tid + BM];
     }
     // epilogue: acc[i][j][r] = C[m = m0 + wm*64 + 16i + (lane&15)][n = n0 + wn*64 + 16j + 4*(lane>>4) + r]
     const int flags = p.flags;
@@ -372,23 +411,35 @@ const char* afr_gemm_kernel_name(int dtype, int flags) {
     return names[dtype == AFR_BF16][a][b];
 }
 
+// bf16: the 256x128 / 8-wave kernel when its grid fills most of the 256 CUs, else 128x128 / 4 waves
+static bool bf16_use_wide(const GemmParams& p) {
+    const long long t = (long long)((p.M + 255) / 256) * ((p.N + 127) / 128) * p.splitk;
+    return t >= 192;
+}
 hipError_t afr_launch_gemm(int dtype, const GemmParams& p, hipStream_t s) {
     const int a = (p.flags & AFR_GEMM_A_KSTRIDED) ? 1 : 0, b = (p.flags & AFR_GEMM_B_KSTRIDED) ? 1 : 0;
-    const int tiles = ((p.M + 127) / 128) * ((p.N + 127) / 128);
-    dim3 grid(tiles * p.splitk, 1, 1), block(256, 1, 1);
-    if (tiles <= 0) return hipSuccess;
-#define LAUNCH(NS, KRN, AL, BL) hipLaunchKernelGGL((NS::KRN<AL, BL>), grid, block, 0, s, p)
+    if (p.M <= 0 || p.N <= 0) return hipSuccess;
     if (dtype == AFR_BF16) {
-        if (!a && !b) LAUNCH(bf16k, gemm_bf16, 0, 0);
-        else if (!a && b) LAUNCH(bf16k, gemm_bf16, 0, 1);
-        else if (a && !b) LAUNCH(bf16k, gemm_bf16, 1, 0);
-        else LAUNCH(bf16k, gemm_bf16, 1, 1);
+        const bool wide = bf16_use_wide(p);
+        const int bm = wide ? 256 : 128;
+        const int tiles = ((p.M + bm - 1) / bm) * ((p.N + 127) / 128);
+        dim3 grid(tiles * p.splitk, 1, 1);
+#define LB(AL, BL) do { if (wide) hipLaunchKernelGGL((bf16k::gemm_bf16<AL, BL, 4>), grid, dim3(512), 0, s, p); \
+                        else hipLaunchKernelGGL((bf16k::gemm_bf16<AL, BL, 2>), grid, dim3(256), 0, s, p); } while (0)
+        if (!a && !b) LB(0, 0);
+        else if (!a && b) LB(0, 1);
+        else if (a && !b) LB(1, 0);
+        else LB(1, 1);
+#undef LB
     } else {
-        if (!a && !b) LAUNCH(f32k, gemm_f32, 0, 0);
-        else if (!a && b) LAUNCH(f32k, gemm_f32, 0, 1);
-        else if (a && !b) LAUNCH(f32k, gemm_f32, 1, 0);
-        else LAUNCH(f32k, gemm_f32, 1, 1);
+        const int tiles = ((p.M + 127) / 128) * ((p.N + 127) / 128);
+        dim3 grid(tiles * p.splitk, 1, 1), block(256, 1, 1);
+#define LF(AL, BL) hipLaunchKernelGGL((f32k::gemm_f32<AL, BL>), grid, block, 0, s, p)
+        if (!a && !b) LF(0, 0);
+        else if (!a && b) LF(0, 1);
+        else if (a && !b) LF(1, 0);
+        else LF(1, 1);
+#undef LF
     }
-#undef LAUNCH
     return hipGetLastError();
 }
