@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "csrc", "libafr.so")
+LIB_PATH = os.environ.get("AFR_LIB_PATH") or os.path.join(HERE, "csrc", "libafr.so")   # override: kernel A/B experiments
 
 AFR_KIND_SHEET, AFR_KIND_GLYPH = 0, 1
 AFR_F32, AFR_BF16 = 0, 1

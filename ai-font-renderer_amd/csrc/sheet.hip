@@ -6,12 +6,12 @@
 // Backward (model.py:309) recomputes that chain in LDS from the same counter-hash dropout stream instead of
 // saving activations (a sample's whole state is <100 KB of LDS), then walks it in reverse.
 //
-// One 256-thread workgroup owns one string at a time and loops over strings (persistent grid, <= 256 blocks):
+// One 1024-thread workgroup owns one string at a time and loops over strings (persistent grid, <= 256 blocks):
 // weights are loaded into LDS once.  Every reduction has a single owner thread and a fixed order -- no atomics:
 //   * attention backward is split by ROW (softmax statistics, delta, dq) and then by COLUMN (dk, dv), each
 //     recomputing the scores it needs, so dv/dk need no scatter;
 //   * the 10 small parameter gradients accumulate across the block's strings in registers (dEmb in LDS, row v
-//     owned by thread slot v%8) and leave as one partial slab per block, summed in block order by reduce_slabs.
+//     owned by thread slot v%32) and leave as one partial slab per block, summed in block order by reduce_slabs.
 // E=32, 4 heads of 8, fc1 width 64 are compile-time (the reference hard-codes them: model.py:79,81,148).
 #include "afr_common.h"
 #include "../../include/afr.h"
@@ -19,6 +19,11 @@
 namespace {
 constexpr int E = 32, H = 4, D = 8, F = 64, QKV = 96;
 constexpr int SE = 33, SQ = 97;                 // padded LDS row strides
+#ifndef AFR_SHEET_NT
+#define AFR_SHEET_NT 1024
+#endif
+constexpr int NT = AFR_SHEET_NT;                // threads per workgroup: many waves hide the LDS/FMA latencies of the serial phases
+constexpr int NG = NT / 32;                     // 32-lane column groups (accumulator ownership)
 constexpr int W_FLOATS = QKV * SE + QKV + E * SE + E + E + E + F * SE + F;   // weights block
 
 struct Wts { float *Win, *bin, *Wo, *bo, *lg, *lb, *W1, *b1; };
@@ -30,9 +35,9 @@ __device__ __forceinline__ Wts carve_weights(float* sm) {
     return w;
 }
 __device__ __forceinline__ void load_weights(const Wts& w, const SheetParams& P, int tid) {
-    for (int i = tid; i < QKV * E; i += 256) w.Win[(i >> 5) * SE + (i & 31)] = P.w_in[i];
-    for (int i = tid; i < E * E; i += 256) w.Wo[(i >> 5) * SE + (i & 31)] = P.w_o[i];
-    for (int i = tid; i < F * E; i += 256) w.W1[(i >> 5) * SE + (i & 31)] = P.w1[i];
+    for (int i = tid; i < QKV * E; i += NT) w.Win[(i >> 5) * SE + (i & 31)] = P.w_in[i];
+    for (int i = tid; i < E * E; i += NT) w.Wo[(i >> 5) * SE + (i & 31)] = P.w_o[i];
+    for (int i = tid; i < F * E; i += NT) w.W1[(i >> 5) * SE + (i & 31)] = P.w1[i];
     if (tid < QKV) w.bin[tid] = P.b_in[tid];
     if (tid < E) { w.bo[tid] = P.b_o[tid]; w.lg[tid] = P.ln_g[tid]; w.lb[tid] = P.ln_b[tid]; }
     if (tid < F) w.b1[tid] = P.b1[tid];
@@ -48,7 +53,7 @@ __device__ __forceinline__ void ph_tokens(int* tok, const int64_t* x, int ldx, i
 }
 // e = dropout(Emb[x]) + P[:L]                                                  (model.py:167-172)
 __device__ __forceinline__ void ph_embed(float* e, const int* tok, const SheetParams& P, const SheetDrop& dr, int b, int L, int tid) {
-    for (int i = tid; i < L * E; i += 256) {
+    for (int i = tid; i < L * E; i += NT) {
         const int l = i >> 5, c = i & 31;
         float v = P.emb[tok[l] * E + c];
         if (dr.training) v = afr_keep((uint64_t)b * L * E + i, dr.key_e, dr.thr_e) ? v * dr.sc_e : 0.f;
@@ -57,7 +62,7 @@ __device__ __forceinline__ void ph_embed(float* e, const int* tok, const SheetPa
 }
 // qkv = e . W_in^T + b_in                                                       (packed in-proj of nn.MultiheadAttention)
 __device__ __forceinline__ void ph_inproj(float* qkv, const float* e, const Wts& w, int L, int tid) {
-    for (int i = tid; i < L * QKV; i += 256) {
+    for (int i = tid; i < L * QKV; i += NT) {
         const int l = i / QKV, j = i - l * QKV;
         float a = w.bin[j];
 #pragma unroll
@@ -70,25 +75,27 @@ __device__ __forceinline__ float attn_mask(const SheetDrop& dr, int b, int h, in
     const uint64_t idx = (((uint64_t)b * H + h) * L + i) * L + j;
     return afr_keep(idx, dr.key_a, dr.thr_a) ? dr.sc_a : 0.f;
 }
-// o = concat_h( dropout(softmax((q/sqrt(D)) k^T)) v )      one thread per (head, query row)
+// o = concat_h( dropout(softmax((q/sqrt(D)) k^T)) v )      two adjacent lanes per (head, query row), keys split even/odd
 __device__ __forceinline__ void ph_attention(float* o, const float* qkv, const SheetDrop& dr, int b, int L, int tid) {
     const float scale = 0.35355339059327373f;    // sqrt(1/8), applied to q as torch does
-    for (int r = tid; r < H * L; r += 256) {
+    for (int rr = tid; rr < 2 * H * L; rr += NT) {
+        const int r = rr >> 1, part = rr & 1;
         const int h = r / L, i = r - h * L;
         float q[D];
 #pragma unroll
         for (int d = 0; d < D; ++d) q[d] = qkv[i * SQ + h * D + d] * scale;
         float mx = -INFINITY;
-        for (int j = 0; j < L; ++j) {
+        for (int j = part; j < L; j += 2) {
             float s = 0.f;
 #pragma unroll
             for (int d = 0; d < D; ++d) s = fmaf(q[d], qkv[j * SQ + E + h * D + d], s);
             mx = fmaxf(mx, s);
         }
+        mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
         float sum = 0.f, acc[D];
 #pragma unroll
         for (int d = 0; d < D; ++d) acc[d] = 0.f;
-        for (int j = 0; j < L; ++j) {
+        for (int j = part; j < L; j += 2) {
             float s = 0.f;
 #pragma unroll
             for (int d = 0; d < D; ++d) s = fmaf(q[d], qkv[j * SQ + E + h * D + d], s);
@@ -98,14 +105,18 @@ __device__ __forceinline__ void ph_attention(float* o, const float* qkv, const S
 #pragma unroll
             for (int d = 0; d < D; ++d) acc[d] = fmaf(pm, qkv[j * SQ + 2 * E + h * D + d], acc[d]);
         }
+        sum += __shfl_xor(sum, 1, 64);
         const float inv = 1.f / sum;
 #pragma unroll
-        for (int d = 0; d < D; ++d) o[i * SE + h * D + d] = acc[d] * inv;
+        for (int d = 0; d < D; ++d) {
+            const float a = acc[d] + __shfl_xor(acc[d], 1, 64);
+            if (part == 0) o[i * SE + h * D + d] = a * inv;
+        }
     }
 }
 // r = e + o . W_o^T + b_o                                                       (model.py:176-180)
 __device__ __forceinline__ void ph_outproj_res(float* r, const float* e, const float* o, const Wts& w, int L, int tid) {
-    for (int i = tid; i < L * E; i += 256) {
+    for (int i = tid; i < L * E; i += NT) {
         const int l = i >> 5, c = i & 31;
         float a = w.bo[c];
 #pragma unroll
@@ -148,7 +159,7 @@ __device__ __forceinline__ float fc1_pre(const float* n, const Wts& w, int l, in
 
 // ------------------------------------------------------------------------------------------ forward kernel
 template <typename T>
-__global__ __launch_bounds__(256) void sheet_fwd_kernel(SheetDims dm, SheetParams P, SheetDrop dr, const int64_t* __restrict__ x,
+__global__ __launch_bounds__(NT) void sheet_fwd_kernel(SheetDims dm, SheetParams P, SheetDrop dr, const int64_t* __restrict__ x,
                                                         int ldx, int B, T* __restrict__ z, float eps, uint32_t* err) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int tid = threadIdx.x, L = dm.L;
@@ -176,12 +187,12 @@ __global__ __launch_bounds__(256) void sheet_fwd_kernel(SheetDims dm, SheetParam
         ph_layernorm(r, n, rstd, w, L, eps, tid);
         __syncthreads();
         T* zr = z + (size_t)b * Kz;
-        for (int i = tid; i < L * F; i += 256) {                    // fc1 + ReLU + dropout, model.py:183-184
+        for (int i = tid; i < L * F; i += NT) {                    // fc1 + ReLU + dropout, model.py:183-184
             const int l = i >> 6, j = i & 63;
             const float f = fmaxf(fc1_pre(n, w, l, j), 0.f);
             zr[i] = (T)(f * fc_mask(dr, b, L, i));
         }
-        for (size_t i = (size_t)L * F + tid; i < Kz; i += 256) zr[i] = (T)0.f;   // zero-pad branch, model.py:190-193
+        for (size_t i = (size_t)L * F + tid; i < Kz; i += NT) zr[i] = (T)0.f;   // zero-pad branch, model.py:190-193
         __syncthreads();
     }
 }
@@ -192,7 +203,7 @@ __device__ __forceinline__ float dqkv_at(const float* dq, const float* big, int 
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void sheet_bwd_kernel(SheetDims dm, SheetParams P, SheetDrop dr, const int64_t* __restrict__ x,
+__global__ __launch_bounds__(NT) void sheet_bwd_kernel(SheetDims dm, SheetParams P, SheetDrop dr, const int64_t* __restrict__ x,
                                                         int ldx, int B, const T* __restrict__ dz, float eps,
                                                         float* __restrict__ slabs, SheetSlabOff so) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -212,19 +223,20 @@ __global__ __launch_bounds__(256) void sheet_bwd_kernel(SheetDims dm, SheetParam
     float* nbuf = big;                 // n  [L][33]
     float* df = big + L * SE;          // df [L][64]
     load_weights(w, P, tid);
-    for (int i = tid; i < dm.vocab * E; i += 256) demb[i] = 0.f;
+    for (int i = tid; i < dm.vocab * E; i += NT) demb[i] = 0.f;
 
-    const int c32 = tid & 31, g8 = tid >> 5;
-    float aW1[8], aWo[4], aWin[12], aPos[15];
+    const int c32 = tid & 31, g8 = tid >> 5;          // g8: column group 0..NG-1
+    constexpr int KW1 = F / NG, KWO = E / NG, KWIN = QKV / NG, KPOS = (120 + NG - 1) / NG;
+    float aW1[KW1], aWo[KWO], aWin[KWIN], aPos[KPOS];
     float a_b1 = 0.f, a_bo = 0.f, a_g = 0.f, a_b = 0.f, a_bin = 0.f;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) aW1[k] = 0.f;
+    for (int k = 0; k < KW1; ++k) aW1[k] = 0.f;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) aWo[k] = 0.f;
+    for (int k = 0; k < KWO; ++k) aWo[k] = 0.f;
 #pragma unroll
-    for (int k = 0; k < 12; ++k) aWin[k] = 0.f;
+    for (int k = 0; k < KWIN; ++k) aWin[k] = 0.f;
 #pragma unroll
-    for (int k = 0; k < 15; ++k) aPos[k] = 0.f;
+    for (int k = 0; k < KPOS; ++k) aPos[k] = 0.f;
     const float scale = 0.35355339059327373f;
     const size_t Kz = (size_t)dm.Lmax * F;
 
@@ -244,7 +256,7 @@ __global__ __launch_bounds__(256) void sheet_bwd_kernel(SheetDims dm, SheetParam
         __syncthreads();
         // ---- df = dz * dropout-mask * [pre>0]
         const T* dzr = dz + (size_t)b * Kz;
-        for (int i = tid; i < L * F; i += 256) {
+        for (int i = tid; i < L * F; i += NT) {
             const int l = i >> 6, j = i & 63;
             const float pre = fc1_pre(nbuf, w, l, j);
             df[i] = pre > 0.f ? (float)dzr[i] * fc_mask(dr, b, L, i) : 0.f;
@@ -254,10 +266,10 @@ __global__ __launch_bounds__(256) void sheet_bwd_kernel(SheetDims dm, SheetParam
         for (int l = 0; l < L; ++l) {
             const float nv = nbuf[l * SE + c32];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) aW1[k] = fmaf(df[l * F + g8 + 8 * k], nv, aW1[k]);
+            for (int k = 0; k < KW1; ++k) aW1[k] = fmaf(df[l * F + g8 + NG * k], nv, aW1[k]);
         }
         if (tid < F) { float a = 0.f; for (int l = 0; l < L; ++l) a += df[l * F + tid]; a_b1 += a; }
-        for (int i = tid; i < L * E; i += 256) {
+        for (int i = tid; i < L * E; i += NT) {
             const int l = i >> 5, c = i & 31;
             float a = 0.f;
 #pragma unroll
@@ -285,11 +297,11 @@ __global__ __launch_bounds__(256) void sheet_bwd_kernel(SheetDims dm, SheetParam
         for (int l = 0; l < L; ++l) {
             const float ov = o[l * SE + c32];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) aWo[k] = fmaf(dn[l * SE + g8 + 8 * k], ov, aWo[k]);
+            for (int k = 0; k < KWO; ++k) aWo[k] = fmaf(dn[l * SE + g8 + NG * k], ov, aWo[k]);
         }
         if (tid < E) { float a = 0.f; for (int l = 0; l < L; ++l) a += dn[l * SE + tid]; a_bo += a; }
         __syncthreads();                                     // all reads of xhat (LN backward) are done
-        for (int i = tid; i < L * E; i += 256) {
+        for (int i = tid; i < L * E; i += NT) {
             const int l = i >> 5, c = i & 31;
             float a = 0.f;
 #pragma unroll
@@ -300,20 +312,23 @@ __global__ __launch_bounds__(256) void sheet_bwd_kernel(SheetDims dm, SheetParam
         ph_inproj(big, e, w, L, tid);                        // recompute qkv
         __syncthreads();
         // ---- attention backward, by ROW: softmax stats, delta = sum_j dA.A, dq      (dq -> `o` buffer)
-        for (int r = tid; r < H * L; r += 256) {
+        //      two adjacent lanes per (head, query row): keys split even/odd, combined with xor-1 shuffles
+        for (int rr = tid; rr < 2 * H * L; rr += NT) {
+            const int r = rr >> 1, part = rr & 1;
             const int h = r / L, i = r - h * L;
             float q[D], dO[D];
 #pragma unroll
             for (int d = 0; d < D; ++d) { q[d] = big[i * SQ + h * D + d] * scale; dO[d] = xh[i * SE + h * D + d]; }
             float mx = -INFINITY;
-            for (int j = 0; j < L; ++j) {
+            for (int j = part; j < L; j += 2) {
                 float s = 0.f;
 #pragma unroll
                 for (int d = 0; d < D; ++d) s = fmaf(q[d], big[j * SQ + E + h * D + d], s);
                 mx = fmaxf(mx, s);
             }
+            mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
             float sum = 0.f, num = 0.f;
-            for (int j = 0; j < L; ++j) {
+            for (int j = part; j < L; j += 2) {
                 float s = 0.f, dA = 0.f;
 #pragma unroll
                 for (int d = 0; d < D; ++d) {
@@ -324,12 +339,14 @@ __global__ __launch_bounds__(256) void sheet_bwd_kernel(SheetDims dm, SheetParam
                 sum += p;
                 num = fmaf(p, dA * attn_mask(dr, b, h, i, j, L), num);
             }
+            sum += __shfl_xor(sum, 1, 64);
+            num += __shfl_xor(num, 1, 64);
             const float inv = 1.f / sum, delta = num * inv;
-            smax[r] = mx; sinv[r] = inv; sdel[r] = delta;
+            if (part == 0) { smax[r] = mx; sinv[r] = inv; sdel[r] = delta; }
             float dq[D];
 #pragma unroll
             for (int d = 0; d < D; ++d) dq[d] = 0.f;
-            for (int j = 0; j < L; ++j) {
+            for (int j = part; j < L; j += 2) {
                 float s = 0.f, dA = 0.f;
 #pragma unroll
                 for (int d = 0; d < D; ++d) {
@@ -342,16 +359,21 @@ __global__ __launch_bounds__(256) void sheet_bwd_kernel(SheetDims dm, SheetParam
                 for (int d = 0; d < D; ++d) dq[d] = fmaf(dS, big[j * SQ + E + h * D + d], dq[d]);
             }
 #pragma unroll
-            for (int d = 0; d < D; ++d) o[i * SE + h * D + d] = dq[d] * scale;
+            for (int d = 0; d < D; ++d) {
+                const float t2 = dq[d] + __shfl_xor(dq[d], 1, 64);
+                if (part == 0) o[i * SE + h * D + d] = t2 * scale;
+            }
         }
         __syncthreads();
-        // ---- attention backward, by COLUMN: dk_j, dv_j (written over k_j, v_j, which only this thread reads)
-        for (int r = tid; r < H * L; r += 256) {
+        // ---- attention backward, by COLUMN: dk_j, dv_j; two lanes per (head, key), queries split even/odd.  The pair
+        //      reads k_j, v_j into registers first and only then (after the shuffles) lane 0 overwrites them in place.
+        for (int rr = tid; rr < 2 * H * L; rr += NT) {
+            const int r = rr >> 1, part = rr & 1;
             const int h = r / L, j = r - h * L;
             float kk[D], vv[D], dk[D], dv[D];
 #pragma unroll
             for (int d = 0; d < D; ++d) { kk[d] = big[j * SQ + E + h * D + d]; vv[d] = big[j * SQ + 2 * E + h * D + d]; dk[d] = 0.f; dv[d] = 0.f; }
-            for (int i = 0; i < L; ++i) {
+            for (int i = part; i < L; i += 2) {
                 float s = 0.f, dA = 0.f, qs[D], dO[D];
 #pragma unroll
                 for (int d = 0; d < D; ++d) {
@@ -368,17 +390,21 @@ __global__ __launch_bounds__(256) void sheet_bwd_kernel(SheetDims dm, SheetParam
                 for (int d = 0; d < D; ++d) { dk[d] = fmaf(dS, qs[d], dk[d]); dv[d] = fmaf(pm, dO[d], dv[d]); }
             }
 #pragma unroll
-            for (int d = 0; d < D; ++d) { big[j * SQ + E + h * D + d] = dk[d]; big[j * SQ + 2 * E + h * D + d] = dv[d]; }
+            for (int d = 0; d < D; ++d) {
+                const float a1 = dk[d] + __shfl_xor(dk[d], 1, 64);
+                const float a2 = dv[d] + __shfl_xor(dv[d], 1, 64);
+                if (part == 0) { big[j * SQ + E + h * D + d] = a1; big[j * SQ + 2 * E + h * D + d] = a2; }
+            }
         }
         __syncthreads();
         // ---- in-proj backward: dWin += dqkv^T e ; dbin += sum dqkv ; de = dr + dqkv . Win   (de in place over dr)
         for (int l = 0; l < L; ++l) {
             const float ev = e[l * SE + c32];
 #pragma unroll
-            for (int k = 0; k < 12; ++k) aWin[k] = fmaf(dqkv_at(o, big, l, g8 + 8 * k), ev, aWin[k]);
+            for (int k = 0; k < KWIN; ++k) aWin[k] = fmaf(dqkv_at(o, big, l, g8 + NG * k), ev, aWin[k]);
         }
         if (tid < QKV) { float a = 0.f; for (int l = 0; l < L; ++l) a += dqkv_at(o, big, l, tid); a_bin += a; }
-        for (int i = tid; i < L * E; i += 256) {
+        for (int i = tid; i < L * E; i += NT) {
             const int l = i >> 5, c = i & 31;
             float a = dn[l * SE + c];
 #pragma unroll 8
@@ -386,12 +412,12 @@ __global__ __launch_bounds__(256) void sheet_bwd_kernel(SheetDims dm, SheetParam
             dn[l * SE + c] = a;
         }
         __syncthreads();
-        // ---- dP += de ; dEmb[tok] += de * embed-dropout-mask       (row v of dEmb owned by thread slot v%8)
+        // ---- dP += de ; dEmb[tok] += de * embed-dropout-mask       (row v of dEmb owned by thread slot v%NG)
 #pragma unroll
-        for (int k = 0; k < 15; ++k) { const int l = g8 + 8 * k; if (l < L) aPos[k] += dn[l * SE + c32]; }
+        for (int k = 0; k < KPOS; ++k) { const int l = g8 + NG * k; if (l < L) aPos[k] += dn[l * SE + c32]; }
         for (int l = 0; l < L; ++l) {
             const int v = tok[l];
-            if ((v & 7) == g8) {
+            if ((v & (NG - 1)) == g8) {
                 float m = 1.f;
                 if (dr.training) m = afr_keep((uint64_t)b * L * E + l * E + c32, dr.key_e, dr.thr_e) ? dr.sc_e : 0.f;
                 demb[v * E + c32] += dn[l * SE + c32] * m;
@@ -402,17 +428,17 @@ __global__ __launch_bounds__(256) void sheet_bwd_kernel(SheetDims dm, SheetParam
     // ---- one partial slab per block, laid out like the flat parameter buffer (pads were zeroed by the host memset)
     float* S = slabs + (size_t)blockIdx.x * so.total;
 #pragma unroll
-    for (int k = 0; k < 15; ++k) { const int l = g8 + 8 * k; if (l < L) S[so.pos + l * E + c32] = aPos[k]; }
-    for (int i = tid; i < dm.vocab * E; i += 256) S[so.emb + i] = demb[i];
+    for (int k = 0; k < KPOS; ++k) { const int l = g8 + NG * k; if (l < L) S[so.pos + l * E + c32] = aPos[k]; }
+    for (int i = tid; i < dm.vocab * E; i += NT) S[so.emb + i] = demb[i];
 #pragma unroll
-    for (int k = 0; k < 12; ++k) S[so.win + (g8 + 8 * k) * E + c32] = aWin[k];
+    for (int k = 0; k < KWIN; ++k) S[so.win + (g8 + NG * k) * E + c32] = aWin[k];
     if (tid < QKV) S[so.bin + tid] = a_bin;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) S[so.wo + (g8 + 8 * k) * E + c32] = aWo[k];
+    for (int k = 0; k < KWO; ++k) S[so.wo + (g8 + NG * k) * E + c32] = aWo[k];
     if (tid < E) { S[so.bo + tid] = a_bo; S[so.g + tid] = a_g; }
     else if (tid < 2 * E) S[so.b + tid - E] = a_b;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) S[so.w1 + (g8 + 8 * k) * E + c32] = aW1[k];
+    for (int k = 0; k < KW1; ++k) S[so.w1 + (g8 + NG * k) * E + c32] = aW1[k];
     if (tid < F) S[so.b1 + tid] = a_b1;
 }
 }  // namespace
@@ -429,7 +455,7 @@ hipError_t afr_launch_sheet_fwd(int act_dtype, const SheetDims& d, const SheetPa
                                 int ldx, int B, void* z, float ln_eps, uint32_t* err_flag, hipStream_t s) {
     if (B <= 0) return hipSuccess;
     const size_t lds = afr_sheet_fwd_lds_bytes(d);
-    dim3 g(afr_sheet_blocks(B)), blk(256);
+    dim3 g(afr_sheet_blocks(B)), blk(NT);
     hipError_t e;
     if (act_dtype == AFR_BF16) {
         if ((e = hipFuncSetAttribute((const void*)sheet_fwd_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
@@ -448,7 +474,7 @@ hipError_t afr_launch_sheet_bwd(int act_dtype, const SheetDims& d, const SheetPa
     const int nb = afr_sheet_blocks(B);
     hipError_t e = hipMemsetAsync(slabs, 0, (size_t)nb * so.total * sizeof(float), s);
     if (e != hipSuccess) return e;
-    dim3 g(nb), blk(256);
+    dim3 g(nb), blk(NT);
     if (act_dtype == AFR_BF16) {
         if ((e = hipFuncSetAttribute((const void*)sheet_bwd_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
         hipLaunchKernelGGL(sheet_bwd_kernel<bf16_t>, g, blk, lds, s, d, P, dr, x, ldx, B, (const bf16_t*)dz, ln_eps, slabs, so);
