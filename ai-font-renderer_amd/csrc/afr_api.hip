@@ -145,7 +145,7 @@ extern "C" int afr_plan_create(const afr_config* c, afr_plan** out) {
         const size_t Kz = (size_t)L * F;
         if (c->dtype == AFR_BF16) p->o_shadow = carve((size_t)p->total * 2);
         p->o_err = carve(256);
-        p->o_loss = carve(1040 * sizeof(float));
+        p->o_loss = carve(((size_t)((B + 127) / 128) * ((Pix + 127) / 128) + 1040) * sizeof(float));
         p->o_z = carve(B * Kz * ab);
         p->o_u = carve(B * Pix * ab);
         p->o_dz = carve(B * Kz * ab);
@@ -182,7 +182,7 @@ extern "C" int afr_plan_create(const afr_config* c, afr_plan** out) {
         p->font_off = c->n_fonts > 0 ? off_of(p, "font_embedding.weight") : -1;
         if (c->dtype == AFR_BF16) p->o_shadow = carve((size_t)p->total * 2);
         p->o_err = carve(256);
-        p->o_loss = carve(1040 * sizeof(float));
+        p->o_loss = carve(((size_t)((B + 127) / 128) * ((Pix + 127) / 128) + 1040) * sizeof(float));
         size_t maxw = (size_t)E, maxn = 0;
         p->o_act.push_back(carve(B * E * ab));
         for (int i = 0; i < c->n_hidden; ++i) {
@@ -328,15 +328,21 @@ extern "C" int afr_profile_dump(afr_plan* p, char* buf, int cap) {
 }
 
 // ------------------------------------------------------------------------------------ helpers
+struct FusedLoss { const void* target; int tdtype; int64_t mean_elems; float* loss_accum; };
 static inline const void* weight_ptr(const afr_plan* p, int64_t off) {
     if (p->cfg.dtype == AFR_BF16) return p->ws + p->o_shadow + (size_t)off * 2;
     return p->P + off;
 }
 static int run_gemm(afr_plan* p, hipStream_t s, int flags, const void* A, const void* B, void* C, const float* bias,
                     const void* aux, int M, int N, int K, int lda, int ldb, int ldc, int ldaux, int splitk,
-                    long long slab_stride, float* colsum = nullptr, long long colsum_stride = 0) {
+                    long long slab_stride, float* colsum = nullptr, long long colsum_stride = 0, const FusedLoss* fl = nullptr) {
     GemmParams g;
     g.colsum = colsum; g.colsum_stride = colsum_stride;
+    if (fl) {
+        float* scratch = (float*)(p->ws + p->o_loss);
+        g.mse_target = fl->target; g.mse_target_dtype = fl->tdtype; g.mse_inv_n = (float)(1.0 / (double)fl->mean_elems);
+        g.mse_partial = scratch + 1040; g.mse_counter = reinterpret_cast<unsigned*>(scratch + 1032); g.mse_loss_accum = fl->loss_accum;
+    }
     g.A = A; g.B = B; g.C = C; g.bias = bias; g.aux = aux;
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldaux = ldaux;
     g.flags = flags; g.splitk = splitk; g.slab_stride = slab_stride;
@@ -403,8 +409,8 @@ static SheetParams sheet_params(const afr_plan* p) {
 }
 
 // ------------------------------------------------------------------------------------- forward
-extern "C" int afr_forward(afr_plan* p, const int64_t* x, const int64_t* font, int B, int L, float* y, int training,
-                           uint64_t step, void* stream) {
+static int forward_impl(afr_plan* p, const int64_t* x, const int64_t* font, int B, int L, float* y, int training,
+                        uint64_t step, void* stream, const FusedLoss* fl) {
     if (!p || !p->P) return fail(AFR_ESTATE, "plan has no bound parameters");
     if (!x) return fail(AFR_EINVAL, "x is null");
     if (B <= 0 || B > p->cfg.max_batch) return fail(AFR_EINVAL, "batch %d outside 1..max_batch=%d", B, p->cfg.max_batch);
@@ -425,7 +431,7 @@ extern "C" int afr_forward(afr_plan* p, const int64_t* x, const int64_t* font, i
         }
         const int Kz = c.max_length * c.fc_dim;
         int rc = run_gemm(p, s, AFR_GEMM_BIAS | ob, z, weight_ptr(p, p->s_wout), u, p->P + p->s_bout, nullptr, B, Pix, Kz,
-                          Kz, Kz, Pix, 0, 1, 0);
+                          Kz, Kz, Pix, 0, 1, 0, nullptr, 0, fl);
         if (rc) return rc;
         p->last_L = Lc;
         p->last_ldx = L;
@@ -443,7 +449,7 @@ extern "C" int afr_forward(afr_plan* p, const int64_t* x, const int64_t* font, i
             const bool last = (i == nl - 1);
             void* outp = last ? u : (void*)(p->ws + p->o_act[i + 1]);
             int rc = run_gemm(p, s, AFR_GEMM_BIAS | (last ? 0 : AFR_GEMM_RELU) | ob, h, weight_ptr(p, l.w_off), outp,
-                              p->P + l.b_off, nullptr, B, l.N, l.K, l.K, l.K, l.N, 0, 1, 0);
+                              p->P + l.b_off, nullptr, B, l.N, l.K, l.K, l.K, l.N, 0, 1, 0, nullptr, 0, last ? fl : nullptr);
             if (rc) return rc;
             h = outp;
         }
@@ -454,8 +460,12 @@ extern "C" int afr_forward(afr_plan* p, const int64_t* x, const int64_t* font, i
         HIPCHK(afr_launch_clamp_out(c.dtype, u, y, (long long)B * Pix, s));
     }
     p->last_x = x; p->last_font = font; p->last_B = B; p->last_training = training; p->last_step = step;
-    p->have_du = false;
+    p->have_du = fl != nullptr;      // with the loss fused into the last layer's epilogue the buffer already holds du
     return AFR_OK;
+}
+extern "C" int afr_forward(afr_plan* p, const int64_t* x, const int64_t* font, int B, int L, float* y, int training,
+                           uint64_t step, void* stream) {
+    return forward_impl(p, x, font, B, L, y, training, step, stream, nullptr);
 }
 
 // --------------------------------------------------------------------------------- loss + grad
@@ -567,8 +577,12 @@ extern "C" int afr_train_step(afr_plan* p, const int64_t* x, const int64_t* font
                               int L, int64_t mean_elems, float* loss_accum, uint64_t step, int do_step, float lr, float b1,
                               float b2, float eps, float wd, int64_t t, void* stream) {
     int rc;
-    if ((rc = afr_forward(p, x, font, B, L, nullptr, 1, step, stream))) return rc;
-    if ((rc = afr_loss_grad(p, target, tdtype, B, mean_elems, loss_accum, stream))) return rc;
+    if (!target || !loss_accum) return fail(AFR_EINVAL, "target and loss_accum are required");
+    if (tdtype != AFR_TARGET_U8 && tdtype != AFR_TARGET_F32) return fail(AFR_EINVAL, "bad target dtype");
+    if (mean_elems <= 0) return fail(AFR_EINVAL, "mean_elems must be positive");
+    // the loss and its gradient are computed in the epilogue of the last forward GEMM: u never touches HBM
+    FusedLoss fl{target, tdtype, mean_elems, loss_accum};
+    if ((rc = forward_impl(p, x, font, B, L, nullptr, 1, step, stream, &fl))) return rc;
     if ((rc = afr_backward(p, stream))) return rc;
     if (do_step && (rc = afr_adamw_step(p, lr, b1, b2, eps, wd, t, 1.f, stream))) return rc;
     return AFR_OK;
@@ -610,7 +624,7 @@ extern "C" int afr_op_gemm(int dtype, int flags, const void* A, const void* B, v
     if (M <= 0 || N <= 0 || K <= 0 || splitk < 1) return fail(AFR_EINVAL, "bad GEMM extents");
     const int v = dtype == AFR_BF16 ? 8 : 4;
     const bool ak = flags & AFR_GEMM_A_KSTRIDED, bk = flags & AFR_GEMM_B_KSTRIDED;
-    if ((ak ? M : K) % v || (bk ? N : K) % v || lda % v || ldb % v || N % 4 || ldc % 4)
+    if ((ak ? M : K) % v || (bk ? N : K) % v || lda % v || ldb % v || N % v || ldc % v)
         return fail(AFR_EUNSUPPORTED, "contiguous extents and leading dimensions must be multiples of %d", v);
     if (splitk > 1 && (flags & (AFR_GEMM_BIAS | AFR_GEMM_RELU | AFR_GEMM_RELU_MASK | AFR_GEMM_OUT_BF16)))
         return fail(AFR_EINVAL, "split-K output is plain f32 partial slabs");

@@ -55,6 +55,36 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// Block-level finish of a loss reduction: `block_sum` (valid in thread 0) is published as this block's partial; the
+// LAST block to arrive sums all partials in block order (deterministic) and adds sum * inv_n to *loss_accum.
+// Hand-off form: sc1 (write-through) partial store, drained, agent-scope ticket; the reader uses sc1 loads only
+// (cdna_hip_programming.md Guideline 16 R1: no release fence -- it would flush every dirty line of the XCD's L2).
+// Must be called by all threads of the block; `sh` is >= blockDim.x floats of LDS free for use.
+__device__ __forceinline__ void loss_block_finish(float block_sum, float* partial, unsigned* counter, float* loss_accum,
+                                                  float inv_n, float* sh) {
+    __shared__ unsigned ticket_;
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(partial + blockIdx.x, block_sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        ticket_ = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (ticket_ != gridDim.x - 1) return;
+    float a = 0.f;
+    for (int i = threadIdx.x; i < (int)gridDim.x; i += blockDim.x)
+        a += __hip_atomic_load(partial + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    sh[threadIdx.x] = a;
+    __syncthreads();
+    for (int o = blockDim.x >> 1; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        loss_accum[0] += sh[0] * inv_n;
+        __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm for the next call
+    }
+}
+
 __device__ __forceinline__ float bf16_to_f32(bf16_t x) { return (float)x; }
 __device__ __forceinline__ bf16_t f32_to_bf16(float x) { return (bf16_t)x; }
 
@@ -71,6 +101,14 @@ struct GemmParams {
     // optional fused bias gradient (A must be k-strided): colsum[z*colsum_stride + m] = sum_k A(m,k) over split z
     float* colsum = nullptr;
     long long colsum_stride = 0;
+    // optional fused loss (last forward layer of a training step): instead of u = A.B^T + bias the epilogue writes
+    // du = 2 (clamp(u,0,1) - t) / mean_elems * [0<=u<=1] and accumulates the MSE (reference model.py:156,268-270)
+    const void* mse_target = nullptr;   // [M][N] uint8 or float32
+    int mse_target_dtype = 0;           // AFR_TARGET_*
+    float mse_inv_n = 0.f;              // 1 / mean_elems
+    float* mse_partial = nullptr;       // per-block partial sums (>= grid floats)
+    unsigned* mse_counter = nullptr;    // arrival counter, zero on entry, re-armed by the last block
+    float* mse_loss_accum = nullptr;    // device scalar: += sum(partials) / mean_elems
 };
 hipError_t afr_launch_gemm(int dtype, const GemmParams& p, hipStream_t s);
 const char* afr_gemm_kernel_name(int dtype, int flags);

@@ -229,34 +229,11 @@ __global__ __launch_bounds__(256) void mse_grad_kernel(const T* __restrict__ u, 
         }
     }
     __shared__ float wsum[4];
-    __shared__ unsigned ticket;
+    __shared__ float sh[256];
     lsum = wave_sum(lsum);
     if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = lsum;
     __syncthreads();
-    // publish this block's partial, take a ticket; the LAST arriver sums all partials in block order (deterministic)
-    // and adds the mean to *loss_accum.  Hand-off form: sc1 payload store, drained, then an agent-scope ticket; the
-    // reader uses sc1 loads only (cdna_hip_programming.md Guideline 16 R1 -- no release fence, which would flush
-    // every dirty du line of the XCD's L2 per block).
-    if (threadIdx.x == 0) {
-        __hip_atomic_store(partial + blockIdx.x, (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the write-through (sc1) store has landed before the ticket
-        ticket = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    __syncthreads();
-    if (ticket != gridDim.x - 1) return;
-    __shared__ float sh[256];                                 // every load of the partials below is an sc1 (agent) load
-    float a = 0.f;
-    for (int i = threadIdx.x; i < (int)gridDim.x; i += 256) a += __hip_atomic_load(partial + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    sh[threadIdx.x] = a;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        loss_accum[0] += sh[0] * inv_n;
-        __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm for the next call
-    }
+    loss_block_finish((wsum[0] + wsum[1]) + (wsum[2] + wsum[3]), partial, counter, loss_accum, inv_n, sh);
 }
 int afr_mse_blocks(long long rows, long long cols) { return grid_for(rows * cols / 8, 256, 1024); }
 hipError_t afr_launch_mse_grad(int act_dtype, const void* u, const void* target, int target_dtype, void* du,

@@ -160,9 +160,12 @@ __global__ __launch_bounds__(256) void gemm_f32(GemmParams p) {
     // epilogue: D[row = (r&3) + 8*(r>>2) + 4*(lane>>5)][col = lane&31]; rows are m, columns n
     const int flags = p.flags;
     const bool out_bf16 = flags & AFR_GEMM_OUT_BF16;
+    const bool mse = p.mse_target != nullptr;
     float* Cf = reinterpret_cast<float*>(p.C) + (size_t)z * p.slab_stride;
     bf16_t* Cb = reinterpret_cast<bf16_t*>(p.C);
     const float* aux = reinterpret_cast<const float*>(p.aux);
+    float lsum = 0.f;
+    const float g2 = 2.f * p.mse_inv_n;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -177,10 +180,26 @@ __global__ __launch_bounds__(256) void gemm_f32(GemmParams p) {
                 float v = acc[i][j][r] + bias;
                 if (flags & AFR_GEMM_RELU) v = fmaxf(v, 0.f);
                 if (flags & AFR_GEMM_RELU_MASK) v = (aux[(size_t)m * p.ldaux + n] > 0.f) ? v : 0.f;
+                if (mse) {
+                    if (out_bf16) v = (float)(bf16_t)v;
+                    const size_t ti = (size_t)m * p.N + n;
+                    const float t = p.mse_target_dtype == AFR_TARGET_U8 ? (float)reinterpret_cast<const uint8_t*>(p.mse_target)[ti] / 255.0f
+                                                                        : reinterpret_cast<const float*>(p.mse_target)[ti];
+                    const float diff = fminf(fmaxf(v, 0.f), 1.f) - t;
+                    lsum += diff * diff;
+                    v = (v >= 0.f && v <= 1.f) ? g2 * diff : 0.f;
+                }
                 if (out_bf16) Cb[(size_t)m * p.ldc + n] = f32_to_bf16(v);
                 else Cf[(size_t)m * p.ldc + n] = v;
             }
         }
+    if (mse) {
+        __syncthreads();
+        lsum = wave_sum(lsum);
+        if (lane == 0) smem[wid] = lsum;
+        __syncthreads();
+        loss_block_finish((smem[0] + smem[1]) + (smem[2] + smem[3]), p.mse_partial, p.mse_counter, p.mse_loss_accum, p.mse_inv_n, smem + 16);
+    }
 }
 }  // namespace f32k
 
@@ -302,59 +321,101 @@ __global__ __launch_bounds__(128 * WM, 2) void gemm_bf16(GemmParams p) {
             stage_inst<BLAY>(rB, S + ASUB * SUB, p.ldb, p.N, n0, k0, kend, wave * B_PER_WAVE + i, lane);
     };
 
-#pragma unroll
-    for (int t = 0; t < STAGES - 1; ++t)
-        if (t < nt) stage(t, t);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    int slot = 0;
-    for (int t = 0; t < nt; ++t) {
-        // tile t+STAGES-1 streams into the slot whose tile every wave finished reading before the last barrier
-#ifndef AFR_ABLATE_NOLOAD
-        if (t + STAGES - 1 < nt) { int sl = slot + STAGES - 1; if (sl >= STAGES) sl -= STAGES; stage(t + STAGES - 1, sl); }
-#endif
-        const char* S = smem + slot * STAGE_BYTES;
+    auto read_a = [&](const char* S, int ks, bf16x8 (&f)[4]) {
         const char* As = S + (wm >> 1) * SUB;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) f[i] = read_frag<ALAY>(As, (wm & 1) * 64 + 16 * i, ks, lane);
+    };
+    auto read_b = [&](const char* S, int ks, bf16x8 (&f)[4]) {
         const char* Bs = S + ASUB * SUB;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 af[4], bfr[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) af[i] = read_frag<ALAY>(As, (wm & 1) * 64 + 16 * i, ks, lane);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) bfr[j] = read_frag<BLAY>(Bs, wn * 64 + 16 * j, ks, lane);
-            // operands swapped on purpose: D'[n][m] so that a lane owns 4 consecutive n of one row m
+        for (int j = 0; j < 4; ++j) f[j] = read_frag<BLAY>(Bs, wn * 64 + 16 * j, ks, lane);
+    };
+    // operands swapped on purpose: D'[n][m] so that a lane owns 4 consecutive n of one row m
+    auto mma = [&](const bf16x8 (&fa)[4], const bf16x8 (&fb)[4]) {
 #ifndef AFR_ABLATE_NOMFMA
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
 #else
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { asm volatile("" ::"v"(af[i])); asm volatile("" ::"v"(bfr[i])); }
+        for (int i = 0; i < 4; ++i) { asm volatile("" ::"v"(fa[i])); asm volatile("" ::"v"(fb[i])); }
 #endif
-        }
-        if (ALAY == 1 && do_cs) {
-            const int xx = tid % BM, hf = tid / BM;
-            const char* Ac = S + (xx >> 7) * SUB;
-            const int xl = xx & 127;
+    };
+    auto colsum_tile = [&](const char* S) {
+        const int xx = tid % BM, hf = tid / BM;
+        const char* Ac = S + (xx >> 7) * SUB;
+        const int xl = xx & 127;
 #pragma unroll 8
-            for (int kk = 0; kk < BK / 2; ++kk) {
-                const int k = hf * (BK / 2) + kk;
-                cs += (float)*reinterpret_cast<const bf16_t*>(Ac + k * 256 + (((xl >> 4) ^ fswz(k)) << 5) + (xl & 15) * 2);
-            }
+        for (int kk = 0; kk < BK / 2; ++kk) {
+            const int k = hf * (BK / 2) + kk;
+            cs += (float)*reinterpret_cast<const bf16_t*>(Ac + k * 256 + (((xl >> 4) ^ fswz(k)) << 5) + (xl & 15) * 2);
         }
-        // tile t+1 must have landed; with a 3-stage ring the DMA of tile t+2 (the newest A_PER_WAVE+B_PER_WAVE
-        // wave-instructions) stays in flight across the barrier
-        if (STAGES == 3 && t + 2 < nt) {
-            if (A_PER_WAVE + B_PER_WAVE == 6) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        }
+    };
+
+    if (STAGES == 3) {
+        // Software-pipelined ring.  Per K-tile t (slot t%3), each wave:
+        //   A  issues the LDS reads of k-step 1 of tile t          B  runs the MFMAs of k-step 0 (fragments read earlier)
+        //   C  waits until the DMA of tile t+1 has landed (tile t+2 stays in flight: counted vmcnt) and meets the
+        //      other waves at the one barrier of the tile; every wave's reads of tile t are complete by then
+        //   D  re-fills the freed slot with tile t+3                E  issues the reads of k-step 0 of tile t+1
+        //   F  runs the MFMAs of k-step 1
+        // so every MFMA block has the next block's LDS reads in flight under it, and two tiles of DMA are in flight.
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+            if (t < nt) stage(t, t);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        if (++slot == STAGES) slot = 0;
+        bf16x8 a0[4], b0[4], a1[4], b1[4];
+        if (nt > 0) { read_a(smem, 0, a0); read_b(smem, 0, b0); }
+        int slot = 0;
+        for (int t = 0; t < nt; ++t) {
+            const char* S = smem + slot * STAGE_BYTES;
+            read_a(S, 1, a1); read_b(S, 1, b1);                                  // A
+            if (ALAY == 1 && do_cs) colsum_tile(S);
+            mma(a0, b0);                                                          // B
+            if (t + 1 < nt) {
+                if (t + 2 < nt) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");   // C
+                else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+#ifndef AFR_ABLATE_NOLOAD
+                if (t + 3 < nt) stage(t + 3, slot);                               // D
+#endif
+                int ns = slot + 1; if (ns == 3) ns = 0;
+                const char* Sn = smem + ns * STAGE_BYTES;
+                read_a(Sn, 0, a0); read_b(Sn, 0, b0);                             // E
+                slot = ns;
+            }
+            mma(a1, b1);                                                          // F
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    } else {
+        if (nt > 0) stage(0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        int slot = 0;
+        for (int t = 0; t < nt; ++t) {
+            // tile t+1 streams into the other slot, which every wave finished reading before the last barrier
+#ifndef AFR_ABLATE_NOLOAD
+            if (t + 1 < nt) stage(t + 1, slot ^ 1);
+#endif
+            const char* S = smem + slot * STAGE_BYTES;
+            bf16x8 fa[4], fb[4];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                read_a(S, ks, fa); read_b(S, ks, fb);
+                mma(fa, fb);
+            }
+            if (ALAY == 1 && do_cs) colsum_tile(S);
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            slot ^= 1;
+        }
     }
 
     if (ALAY == 1 && do_cs) {
@@ -362,42 +423,93 @@ __global__ __launch_bounds__(128 * WM, 2) void gemm_bf16(GemmParams p) {
         red[tid] = cs;
         __syncthreads();
         if (tid < BM && m0 + tid < p.M) p.colsum[(size_t)z * p.colsum_stride + m0 + tid] = red[tid] + red[tid + BM];
+        __syncthreads();                       // the staging below reuses this LDS
     }
-    // epilogue: acc[i][j][r] = C[m = m0 + wm*64 + 16i + (lane&15)][n = n0 + wn*64 + 16j + 4*(lane>>4) + r]
+    // Epilogue through LDS: the MFMA accumulators hold 4 consecutive n of 16 different rows per lane-group, which as
+    // direct stores would be 32-byte pieces.  Each wave parks its 64x64 f32 tile in its own 16 KiB of LDS (16-B chunks
+    // XOR-swizzled by row: conflict-free both ways) and streams it out row-contiguous: 8 lanes x 8 values = one 64-col
+    // row, so stores (and the aux / target loads of the fused tails) are whole 128-B / 256-B row segments.
     const int flags = p.flags;
     const bool out_bf16 = flags & AFR_GEMM_OUT_BF16;
-    float* Cf = reinterpret_cast<float*>(p.C) + (size_t)z * p.slab_stride;
-    bf16_t* Cb = reinterpret_cast<bf16_t*>(p.C);
-    const bf16_t* aux = reinterpret_cast<const bf16_t*>(p.aux);
+    const bool mse = p.mse_target != nullptr;
+    float* Wt = reinterpret_cast<float*>(smem) + wave * 4096;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int m = m0 + wm * 64 + 16 * i + (lane & 15);
-        if (m >= p.M) continue;
+        const int ml = 16 * i + (lane & 15);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int n = n0 + wn * 64 + 16 * j + 4 * (lane >> 4);
-            if (n >= p.N) continue;
+            const int nl = 16 * j + 4 * (lane >> 4);
+            const int n = n0 + wn * 64 + nl;
             f32x4 v = acc[i][j];
-            if (flags & AFR_GEMM_BIAS) {
-                const float4 b = *reinterpret_cast<const float4*>(p.bias + n);
-                v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+            if ((flags & AFR_GEMM_BIAS) && n < p.N) {
+                const float4 bb = *reinterpret_cast<const float4*>(p.bias + n);
+                v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
             }
             if (flags & AFR_GEMM_RELU) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
             }
-            if (flags & AFR_GEMM_RELU_MASK) {
-                const bf16x4 a = *reinterpret_cast<const bf16x4*>(aux + (size_t)m * p.ldaux + n);
+            *reinterpret_cast<f32x4*>(Wt + ml * 64 + (((nl >> 2) ^ (ml & 15)) << 2)) = v;
+        }
+    }
+    float* Cf = reinterpret_cast<float*>(p.C) + (size_t)z * p.slab_stride;
+    bf16_t* Cb = reinterpret_cast<bf16_t*>(p.C);
+    const bf16_t* aux = reinterpret_cast<const bf16_t*>(p.aux);
+    float lsum = 0.f;
+    const float g2 = 2.f * p.mse_inv_n;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = ((float)a[r] > 0.f) ? v[r] : 0.f;
-            }
-            if (out_bf16) {
-                bf16x4 o = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
-                *reinterpret_cast<bf16x4*>(Cb + (size_t)m * p.ldc + n) = o;
+    for (int ps = 0; ps < 8; ++ps) {
+        const int rl = ps * 8 + (lane >> 3), c8 = lane & 7;
+        const f32x4 lo = *reinterpret_cast<const f32x4*>(Wt + rl * 64 + (((2 * c8) ^ (rl & 15)) << 2));
+        const f32x4 hi = *reinterpret_cast<const f32x4*>(Wt + rl * 64 + (((2 * c8 + 1) ^ (rl & 15)) << 2));
+        float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        const int m = m0 + wm * 64 + rl, n = n0 + wn * 64 + 8 * c8;
+        if (m >= p.M || n >= p.N) continue;
+        if (flags & AFR_GEMM_RELU_MASK) {
+            const bf16x8 a = *reinterpret_cast<const bf16x8*>(aux + (size_t)m * p.ldaux + n);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) v[r] = ((float)a[r] > 0.f) ? v[r] : 0.f;
+        }
+        if (mse) {
+            float t[8];
+            const size_t ti = (size_t)m * p.N + n;
+            if (p.mse_target_dtype == AFR_TARGET_U8) {
+                const uint2 w = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint8_t*>(p.mse_target) + ti);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { t[r] = (float)((w.x >> (8 * r)) & 0xFF) / 255.0f; t[4 + r] = (float)((w.y >> (8 * r)) & 0xFF) / 255.0f; }
             } else {
-                *reinterpret_cast<f32x4*>(Cf + (size_t)m * p.ldc + n) = v;
+                const float4 w0 = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.mse_target) + ti);
+                const float4 w1 = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.mse_target) + ti + 4);
+                t[0] = w0.x; t[1] = w0.y; t[2] = w0.z; t[3] = w0.w; t[4] = w1.x; t[5] = w1.y; t[6] = w1.z; t[7] = w1.w;
+            }
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const float u = out_bf16 ? (float)(bf16_t)v[r] : v[r];     // the value the unfused path would store
+                const float diff = fminf(fmaxf(u, 0.f), 1.f) - t[r];
+                lsum += diff * diff;
+                v[r] = (u >= 0.f && u <= 1.f) ? g2 * diff : 0.f;
             }
         }
+        if (out_bf16) {
+            bf16x8 o;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) o[r] = (bf16_t)v[r];
+            *reinterpret_cast<bf16x8*>(Cb + (size_t)m * p.ldc + n) = o;
+        } else {
+            *reinterpret_cast<float4*>(Cf + (size_t)m * p.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
+            *reinterpret_cast<float4*>(Cf + (size_t)m * p.ldc + n + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        }
+    }
+    if (mse) {
+        float* red = reinterpret_cast<float*>(smem);
+        __syncthreads();                       // every wave is done with its staging tile
+        lsum = wave_sum(lsum);
+        if (lane == 0) red[wave] = lsum;
+        __syncthreads();
+        float bs = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) bs += red[w];
+        loss_block_finish(bs, p.mse_partial, p.mse_counter, p.mse_loss_accum, p.mse_inv_n, red + 16);
     }
 }
 }  // namespace bf16k
