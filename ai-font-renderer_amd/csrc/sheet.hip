@@ -18,7 +18,8 @@
 
 namespace {
 constexpr int E = 32, H = 4, D = 8, F = 64, QKV = 96;
-constexpr int SE = 33, SQ = 97;                 // padded LDS row strides
+constexpr int SE = 33, SQ = 100, SD = 36;       // LDS row strides: SE odd (conflict-free column walks); SQ, SD multiples of 4
+                                                // so that a head's 8 q/k/v/dO values are two aligned 16-byte LDS reads
 #ifndef AFR_SHEET_NT
 #define AFR_SHEET_NT 1024
 #endif
@@ -43,6 +44,18 @@ __device__ __forceinline__ void load_weights(const Wts& w, const SheetParams& P,
     if (tid < F) w.b1[tid] = P.b1[tid];
 }
 
+__device__ __forceinline__ void ld8(const float* p, float (&v)[8]) {
+    const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+__device__ __forceinline__ float dot8(const float (&a)[8], const float (&b)[8]) {
+    float s = 0.f;
+#pragma unroll
+    for (int d = 0; d < 8; ++d) s = fmaf(a[d], b[d], s);
+    return s;
+}
+__device__ __forceinline__ int al4(int n) { return (n + 3) & ~3; }
+
 // ---- shared forward pieces (used by both kernels so that backward's recomputation is bit-identical) ----------
 __device__ __forceinline__ void ph_tokens(int* tok, const int64_t* x, int ldx, int b, int L, int vocab, uint32_t* err, int tid) {
     if (tid < L) {
@@ -65,7 +78,7 @@ __device__ __forceinline__ void ph_inproj(float* qkv, const float* e, const Wts&
     for (int i = tid; i < L * QKV; i += NT) {
         const int l = i / QKV, j = i - l * QKV;
         float a = w.bin[j];
-#pragma unroll
+#pragma unroll 8
         for (int c = 0; c < E; ++c) a = fmaf(e[l * SE + c], w.Win[j * SE + c], a);
         qkv[l * SQ + j] = a;
     }
@@ -81,29 +94,29 @@ __device__ __forceinline__ void ph_attention(float* o, const float* qkv, const S
     for (int rr = tid; rr < 2 * H * L; rr += NT) {
         const int r = rr >> 1, part = rr & 1;
         const int h = r / L, i = r - h * L;
-        float q[D];
+        float q[D], kv[D];
+        ld8(qkv + i * SQ + h * D, q);
 #pragma unroll
-        for (int d = 0; d < D; ++d) q[d] = qkv[i * SQ + h * D + d] * scale;
+        for (int d = 0; d < D; ++d) q[d] *= scale;
         float mx = -INFINITY;
+#pragma clang loop unroll_count(2) vectorize(disable) interleave(disable)
         for (int j = part; j < L; j += 2) {
-            float s = 0.f;
-#pragma unroll
-            for (int d = 0; d < D; ++d) s = fmaf(q[d], qkv[j * SQ + E + h * D + d], s);
-            mx = fmaxf(mx, s);
+            ld8(qkv + j * SQ + E + h * D, kv);
+            mx = fmaxf(mx, dot8(q, kv));
         }
         mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
         float sum = 0.f, acc[D];
 #pragma unroll
         for (int d = 0; d < D; ++d) acc[d] = 0.f;
+#pragma clang loop unroll_count(2) vectorize(disable) interleave(disable)
         for (int j = part; j < L; j += 2) {
-            float s = 0.f;
-#pragma unroll
-            for (int d = 0; d < D; ++d) s = fmaf(q[d], qkv[j * SQ + E + h * D + d], s);
-            const float p = expf(s - mx);
+            ld8(qkv + j * SQ + E + h * D, kv);
+            const float p = __expf(dot8(q, kv) - mx);
             sum += p;
             const float pm = p * attn_mask(dr, b, h, i, j, L);
+            ld8(qkv + j * SQ + 2 * E + h * D, kv);
 #pragma unroll
-            for (int d = 0; d < D; ++d) acc[d] = fmaf(pm, qkv[j * SQ + 2 * E + h * D + d], acc[d]);
+            for (int d = 0; d < D; ++d) acc[d] = fmaf(pm, kv[d], acc[d]);
         }
         sum += __shfl_xor(sum, 1, 64);
         const float inv = 1.f / sum;
@@ -119,7 +132,7 @@ __device__ __forceinline__ void ph_outproj_res(float* r, const float* e, const f
     for (int i = tid; i < L * E; i += NT) {
         const int l = i >> 5, c = i & 31;
         float a = w.bo[c];
-#pragma unroll
+#pragma unroll 8
         for (int k = 0; k < E; ++k) a = fmaf(o[l * SE + k], w.Wo[c * SE + k], a);
         r[l * SE + c] = e[l * SE + c] + a;
     }
@@ -129,16 +142,16 @@ __device__ __forceinline__ void ph_layernorm(float* xh, float* n, float* rstd, c
     if (tid < L) {
         float* row = xh + tid * SE;
         float mu = 0.f;
-#pragma unroll
+#pragma unroll 8
         for (int c = 0; c < E; ++c) mu += row[c];
         mu *= (1.f / E);
         float var = 0.f;
-#pragma unroll
+#pragma unroll 8
         for (int c = 0; c < E; ++c) { const float dlt = row[c] - mu; var = fmaf(dlt, dlt, var); }
         var *= (1.f / E);
         const float rs = 1.f / sqrtf(var + eps);
         rstd[tid] = rs;
-#pragma unroll
+#pragma unroll 8
         for (int c = 0; c < E; ++c) {
             const float xv = (row[c] - mu) * rs;
             row[c] = xv;
@@ -152,7 +165,7 @@ __device__ __forceinline__ float fc_mask(const SheetDrop& dr, int b, int L, int 
 }
 __device__ __forceinline__ float fc1_pre(const float* n, const Wts& w, int l, int j) {
     float a = w.b1[j];
-#pragma unroll
+#pragma unroll 8
     for (int c = 0; c < E; ++c) a = fmaf(n[l * SE + c], w.W1[j * SE + c], a);
     return a;
 }
@@ -165,12 +178,12 @@ __global__ __launch_bounds__(NT) void sheet_fwd_kernel(SheetDims dm, SheetParams
     const int tid = threadIdx.x, L = dm.L;
     const Wts w = carve_weights(sm);
     float* e = sm + W_FLOATS;
-    float* qkv = e + L * SE;
+    float* qkv = e + al4(L * SE);
     float* o = qkv + L * SQ;
-    float* r = o + L * SE;
-    float* n = r + L * SE;
-    float* rstd = n + L * SE;
-    int* tok = reinterpret_cast<int*>(rstd + L);
+    float* r = o + al4(L * SE);
+    float* n = r + al4(L * SE);
+    float* rstd = n + al4(L * SE);
+    int* tok = reinterpret_cast<int*>(rstd + al4(L));
     load_weights(w, P, tid);
     const size_t Kz = (size_t)dm.Lmax * F;
     for (int b = blockIdx.x; b < B; b += gridDim.x) {
@@ -210,12 +223,12 @@ __global__ __launch_bounds__(NT) void sheet_bwd_kernel(SheetDims dm, SheetParams
     const int tid = threadIdx.x, L = dm.L;
     const Wts w = carve_weights(sm);
     float* e = sm + W_FLOATS;          // [L][33]   whole sample
-    float* big = e + L * SE;           // [L][97]   qkv  | later n [L][33] + df [L][64] | later qkv again -> dk,dv in place
+    float* big = e + al4(L * SE);      // [L][100]  qkv  | later n [L][33] + df [L][64] | later qkv again -> dk,dv in place
     float* o = big + L * SQ;           // [L][33]   o    | later dq
-    float* xh = o + L * SE;            // [L][33]   r -> xhat | later dO (grad wrt attention output o)
-    float* dn = xh + L * SE;           // [L][33]   dn -> dr -> de
-    float* rstd = dn + L * SE;         // [L]
-    float* smax = rstd + L;            // [4L]
+    float* xh = o + al4(L * SE);       // [L][36]   r -> xhat (stride 33) | later dO, grad wrt attention output (stride 36)
+    float* dn = xh + L * SD;           // [L][33]   dn -> dr -> de
+    float* rstd = dn + al4(L * SE);    // [L]
+    float* smax = rstd + al4(L);       // [4L]
     float* sinv = smax + H * L;        // [4L]
     float* sdel = sinv + H * L;        // [4L]
     float* demb = sdel + H * L;        // [vocab][32]
@@ -263,50 +276,60 @@ __global__ __launch_bounds__(NT) void sheet_bwd_kernel(SheetDims dm, SheetParams
         }
         __syncthreads();
         // ---- dW1 += df^T n ; db1 += sum df ; dn = df . W1
+#pragma clang loop unroll_count(4) vectorize(disable) interleave(disable)
         for (int l = 0; l < L; ++l) {
             const float nv = nbuf[l * SE + c32];
 #pragma unroll
             for (int k = 0; k < KW1; ++k) aW1[k] = fmaf(df[l * F + g8 + NG * k], nv, aW1[k]);
         }
-        if (tid < F) { float a = 0.f; for (int l = 0; l < L; ++l) a += df[l * F + tid]; a_b1 += a; }
+        if (tid < F) { float a = 0.f;
+_Pragma("clang loop unroll_count(4) vectorize(disable) interleave(disable)")
+            for (int l = 0; l < L; ++l) a += df[l * F + tid]; a_b1 += a; }
         for (int i = tid; i < L * E; i += NT) {
             const int l = i >> 5, c = i & 31;
             float a = 0.f;
-#pragma unroll
+#pragma unroll 8
             for (int j = 0; j < F; ++j) a = fmaf(df[l * F + j], w.W1[j * SE + c], a);
             dn[l * SE + c] = a;
         }
         __syncthreads();
         // ---- LayerNorm backward: dgamma, dbeta (column owners), then dr in place (row owners)
-        if (tid < E) { float a = 0.f; for (int l = 0; l < L; ++l) a = fmaf(dn[l * SE + tid], xh[l * SE + tid], a); a_g += a; }
-        else if (tid < 2 * E) { const int c = tid - E; float a = 0.f; for (int l = 0; l < L; ++l) a += dn[l * SE + c]; a_b += a; }
+        if (tid < E) { float a = 0.f;
+_Pragma("clang loop unroll_count(4) vectorize(disable) interleave(disable)")
+            for (int l = 0; l < L; ++l) a = fmaf(dn[l * SE + tid], xh[l * SE + tid], a); a_g += a; }
+        else if (tid < 2 * E) { const int c = tid - E; float a = 0.f;
+_Pragma("clang loop unroll_count(4) vectorize(disable) interleave(disable)")
+            for (int l = 0; l < L; ++l) a += dn[l * SE + c]; a_b += a; }
         __syncthreads();
         if (tid < L) {
             float* row = dn + tid * SE;
             const float* xr = xh + tid * SE;
             float m1 = 0.f, m2 = 0.f;
-#pragma unroll
+#pragma unroll 8
             for (int c = 0; c < E; ++c) { const float gv = row[c] * w.lg[c]; m1 += gv; m2 = fmaf(gv, xr[c], m2); }
             m1 *= (1.f / E); m2 *= (1.f / E);
             const float rs = rstd[tid];
-#pragma unroll
+#pragma unroll 8
             for (int c = 0; c < E; ++c) row[c] = (row[c] * w.lg[c] - m1 - xr[c] * m2) * rs;
         }
         __syncthreads();
         // ---- out-proj backward: dWo += dr^T o ; dbo += sum dr ; dO = dr . Wo  (written over xhat, which is dead)
+#pragma clang loop unroll_count(4) vectorize(disable) interleave(disable)
         for (int l = 0; l < L; ++l) {
             const float ov = o[l * SE + c32];
 #pragma unroll
             for (int k = 0; k < KWO; ++k) aWo[k] = fmaf(dn[l * SE + g8 + NG * k], ov, aWo[k]);
         }
-        if (tid < E) { float a = 0.f; for (int l = 0; l < L; ++l) a += dn[l * SE + tid]; a_bo += a; }
+        if (tid < E) { float a = 0.f;
+_Pragma("clang loop unroll_count(4) vectorize(disable) interleave(disable)")
+            for (int l = 0; l < L; ++l) a += dn[l * SE + tid]; a_bo += a; }
         __syncthreads();                                     // all reads of xhat (LN backward) are done
         for (int i = tid; i < L * E; i += NT) {
             const int l = i >> 5, c = i & 31;
             float a = 0.f;
-#pragma unroll
+#pragma unroll 8
             for (int k = 0; k < E; ++k) a = fmaf(dn[l * SE + k], w.Wo[k * SE + c], a);
-            xh[l * SE + c] = a;
+            xh[l * SD + c] = a;
         }
         __syncthreads();                                     // n, df dead; o dead after the dWo loop above
         ph_inproj(big, e, w, L, tid);                        // recompute qkv
@@ -316,28 +339,26 @@ __global__ __launch_bounds__(NT) void sheet_bwd_kernel(SheetDims dm, SheetParams
         for (int rr = tid; rr < 2 * H * L; rr += NT) {
             const int r = rr >> 1, part = rr & 1;
             const int h = r / L, i = r - h * L;
-            float q[D], dO[D];
+            float q[D], dO[D], kk[D], vv[D];
+            ld8(big + i * SQ + h * D, q);
+            ld8(xh + i * SD + h * D, dO);
 #pragma unroll
-            for (int d = 0; d < D; ++d) { q[d] = big[i * SQ + h * D + d] * scale; dO[d] = xh[i * SE + h * D + d]; }
+            for (int d = 0; d < D; ++d) q[d] *= scale;
             float mx = -INFINITY;
-            for (int j = part; j < L; j += 2) {
-                float s = 0.f;
-#pragma unroll
-                for (int d = 0; d < D; ++d) s = fmaf(q[d], big[j * SQ + E + h * D + d], s);
-                mx = fmaxf(mx, s);
+    #pragma clang loop unroll_count(2) vectorize(disable) interleave(disable)
+        for (int j = part; j < L; j += 2) {
+                ld8(big + j * SQ + E + h * D, kk);
+                mx = fmaxf(mx, dot8(q, kk));
             }
             mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
             float sum = 0.f, num = 0.f;
-            for (int j = part; j < L; j += 2) {
-                float s = 0.f, dA = 0.f;
-#pragma unroll
-                for (int d = 0; d < D; ++d) {
-                    s = fmaf(q[d], big[j * SQ + E + h * D + d], s);
-                    dA = fmaf(dO[d], big[j * SQ + 2 * E + h * D + d], dA);
-                }
-                const float p = expf(s - mx);
+    #pragma clang loop unroll_count(2) vectorize(disable) interleave(disable)
+        for (int j = part; j < L; j += 2) {
+                ld8(big + j * SQ + E + h * D, kk);
+                ld8(big + j * SQ + 2 * E + h * D, vv);
+                const float p = __expf(dot8(q, kk) - mx);
                 sum += p;
-                num = fmaf(p, dA * attn_mask(dr, b, h, i, j, L), num);
+                num = fmaf(p, dot8(dO, vv) * attn_mask(dr, b, h, i, j, L), num);
             }
             sum += __shfl_xor(sum, 1, 64);
             num += __shfl_xor(num, 1, 64);
@@ -346,17 +367,14 @@ __global__ __launch_bounds__(NT) void sheet_bwd_kernel(SheetDims dm, SheetParams
             float dq[D];
 #pragma unroll
             for (int d = 0; d < D; ++d) dq[d] = 0.f;
-            for (int j = part; j < L; j += 2) {
-                float s = 0.f, dA = 0.f;
+    #pragma clang loop unroll_count(2) vectorize(disable) interleave(disable)
+        for (int j = part; j < L; j += 2) {
+                ld8(big + j * SQ + E + h * D, kk);
+                ld8(big + j * SQ + 2 * E + h * D, vv);
+                const float p = __expf(dot8(q, kk) - mx) * inv;
+                const float dS = p * (dot8(dO, vv) * attn_mask(dr, b, h, i, j, L) - delta);
 #pragma unroll
-                for (int d = 0; d < D; ++d) {
-                    s = fmaf(q[d], big[j * SQ + E + h * D + d], s);
-                    dA = fmaf(dO[d], big[j * SQ + 2 * E + h * D + d], dA);
-                }
-                const float p = expf(s - mx) * inv;
-                const float dS = p * (dA * attn_mask(dr, b, h, i, j, L) - delta);
-#pragma unroll
-                for (int d = 0; d < D; ++d) dq[d] = fmaf(dS, big[j * SQ + E + h * D + d], dq[d]);
+                for (int d = 0; d < D; ++d) dq[d] = fmaf(dS, kk[d], dq[d]);
             }
 #pragma unroll
             for (int d = 0; d < D; ++d) {
@@ -370,21 +388,20 @@ __global__ __launch_bounds__(NT) void sheet_bwd_kernel(SheetDims dm, SheetParams
         for (int rr = tid; rr < 2 * H * L; rr += NT) {
             const int r = rr >> 1, part = rr & 1;
             const int h = r / L, j = r - h * L;
-            float kk[D], vv[D], dk[D], dv[D];
+            float kk[D], vv[D], dk[D], dv[D], qs[D], dO[D];
+            ld8(big + j * SQ + E + h * D, kk);
+            ld8(big + j * SQ + 2 * E + h * D, vv);
 #pragma unroll
-            for (int d = 0; d < D; ++d) { kk[d] = big[j * SQ + E + h * D + d]; vv[d] = big[j * SQ + 2 * E + h * D + d]; dk[d] = 0.f; dv[d] = 0.f; }
+            for (int d = 0; d < D; ++d) { dk[d] = 0.f; dv[d] = 0.f; }
+#pragma clang loop unroll_count(2) vectorize(disable) interleave(disable)
             for (int i = part; i < L; i += 2) {
-                float s = 0.f, dA = 0.f, qs[D], dO[D];
+                ld8(big + i * SQ + h * D, qs);
+                ld8(xh + i * SD + h * D, dO);
 #pragma unroll
-                for (int d = 0; d < D; ++d) {
-                    qs[d] = big[i * SQ + h * D + d] * scale;
-                    dO[d] = xh[i * SE + h * D + d];
-                    s = fmaf(qs[d], kk[d], s);
-                    dA = fmaf(dO[d], vv[d], dA);
-                }
-                const float p = expf(s - smax[h * L + i]) * sinv[h * L + i];
+                for (int d = 0; d < D; ++d) qs[d] *= scale;
+                const float p = __expf(dot8(qs, kk) - smax[h * L + i]) * sinv[h * L + i];
                 const float m = attn_mask(dr, b, h, i, j, L);
-                const float dS = p * (dA * m - sdel[h * L + i]);
+                const float dS = p * (dot8(dO, vv) * m - sdel[h * L + i]);
                 const float pm = p * m;
 #pragma unroll
                 for (int d = 0; d < D; ++d) { dk[d] = fmaf(dS, qs[d], dk[d]); dv[d] = fmaf(pm, dO[d], dv[d]); }
@@ -398,12 +415,15 @@ __global__ __launch_bounds__(NT) void sheet_bwd_kernel(SheetDims dm, SheetParams
         }
         __syncthreads();
         // ---- in-proj backward: dWin += dqkv^T e ; dbin += sum dqkv ; de = dr + dqkv . Win   (de in place over dr)
+#pragma clang loop unroll_count(4) vectorize(disable) interleave(disable)
         for (int l = 0; l < L; ++l) {
             const float ev = e[l * SE + c32];
 #pragma unroll
             for (int k = 0; k < KWIN; ++k) aWin[k] = fmaf(dqkv_at(o, big, l, g8 + NG * k), ev, aWin[k]);
         }
-        if (tid < QKV) { float a = 0.f; for (int l = 0; l < L; ++l) a += dqkv_at(o, big, l, tid); a_bin += a; }
+        if (tid < QKV) { float a = 0.f;
+_Pragma("clang loop unroll_count(4) vectorize(disable) interleave(disable)")
+            for (int l = 0; l < L; ++l) a += dqkv_at(o, big, l, tid); a_bin += a; }
         for (int i = tid; i < L * E; i += NT) {
             const int l = i >> 5, c = i & 31;
             float a = dn[l * SE + c];
@@ -415,6 +435,7 @@ __global__ __launch_bounds__(NT) void sheet_bwd_kernel(SheetDims dm, SheetParams
         // ---- dP += de ; dEmb[tok] += de * embed-dropout-mask       (row v of dEmb owned by thread slot v%NG)
 #pragma unroll
         for (int k = 0; k < KPOS; ++k) { const int l = g8 + NG * k; if (l < L) aPos[k] += dn[l * SE + c32]; }
+#pragma clang loop unroll_count(4) vectorize(disable) interleave(disable)
         for (int l = 0; l < L; ++l) {
             const int v = tok[l];
             if ((v & (NG - 1)) == g8) {
@@ -444,11 +465,12 @@ __global__ __launch_bounds__(NT) void sheet_bwd_kernel(SheetDims dm, SheetParams
 }  // namespace
 
 int afr_sheet_blocks(int B) { return B < 256 ? B : 256; }
+static inline int al4h(int n) { return (n + 3) & ~3; }
 size_t afr_sheet_fwd_lds_bytes(const SheetDims& d) {
-    return (size_t)(W_FLOATS + 4 * d.L * SE + d.L * SQ + 2 * d.L) * sizeof(float);
+    return (size_t)(W_FLOATS + 4 * al4h(d.L * SE) + d.L * SQ + 2 * al4h(d.L)) * sizeof(float);
 }
 size_t afr_sheet_bwd_lds_bytes(const SheetDims& d) {
-    return (size_t)(W_FLOATS + 4 * d.L * SE + d.L * SQ + d.L + 3 * H * d.L + d.vocab * E + d.L) * sizeof(float);
+    return (size_t)(W_FLOATS + 3 * al4h(d.L * SE) + d.L * SD + d.L * SQ + al4h(d.L) + 3 * H * d.L + d.vocab * E + d.L) * sizeof(float);
 }
 
 hipError_t afr_launch_sheet_fwd(int act_dtype, const SheetDims& d, const SheetParams& P, const SheetDrop& dr, const int64_t* x,
