@@ -47,6 +47,9 @@ SIGNATURES = {
     "afr_loss_grad": (_i32, [_vp, _vp, _i32, _i32, _i64, _vp, _vp]),
     "afr_set_output_grad": (_i32, [_vp, _vp, _i32, _vp]),
     "afr_backward": (_i32, [_vp, _vp]),
+    "afr_backward_stages": (_i32, [_vp]),
+    "afr_backward_stage": (_i32, [_vp, _i32, C.POINTER(_i64), C.POINTER(_i64), _vp]),
+    "afr_forward_loss": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i64, _vp, _u64, _vp]),
     "afr_adamw_step": (_i32, [_vp, _f32, _f32, _f32, _f32, _f32, _i64, _f32, _vp]),
     "afr_train_step": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i64, _vp, _u64, _i32, _f32, _f32, _f32, _f32, _f32, _i64, _vp]),
     "afr_error_flags": (_i32, [_vp, _vp, C.POINTER(C.c_uint32)]),

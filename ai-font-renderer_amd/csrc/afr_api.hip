@@ -65,6 +65,7 @@ struct afr_plan {
     int last_B = 0, last_L = 0, last_ldx = 0, last_training = 0;
     uint64_t last_step = 0;
     bool have_du = false;
+    int next_stage = 0;
     // profiling
     int prof_mode = 0;      // 0 off, 1 every launch, 2 only prof_only
     int prof_only = -1;
@@ -460,6 +461,7 @@ static int forward_impl(afr_plan* p, const int64_t* x, const int64_t* font, int 
         HIPCHK(afr_launch_clamp_out(c.dtype, u, y, (long long)B * Pix, s));
     }
     p->last_x = x; p->last_font = font; p->last_B = B; p->last_training = training; p->last_step = step;
+    p->next_stage = 0;
     p->have_du = fl != nullptr;      // with the loss fused into the last layer's epilogue the buffer already holds du
     return AFR_OK;
 }
@@ -497,10 +499,11 @@ extern "C" int afr_set_output_grad(afr_plan* p, const float* dy, int B, void* st
 }
 
 // ------------------------------------------------------------------------------------ backward
-extern "C" int afr_backward(afr_plan* p, void* stream) {
-    if (!p || !p->P || !p->G) return fail(AFR_ESTATE, "plan has no bound parameter/gradient buffers");
-    if (!p->have_du) return fail(AFR_ESTATE, "afr_backward needs afr_forward + afr_loss_grad first");
-    hipStream_t s = (hipStream_t)stream;
+// Backward runs in STAGES, last layer first; each stage finishes a contiguous range of the flat gradient buffer
+// (its own slab reduction included), so a data-parallel caller can start the all-reduce of that range while the
+// next stage computes.  Glyph: one stage per Linear (the first layer's stage also does the embedding tables).
+// Sheet: stage 0 = fc_output (dW + db), stage 1 = dz GEMM + fused front-end backward.
+static int backward_stage_impl(afr_plan* p, int stage, int64_t* g_off, int64_t* g_len, hipStream_t s) {
     const afr_config& c = p->cfg;
     const int B = p->last_B, Pix = c.out_h * c.out_w;
     const int ob = c.dtype == AFR_BF16 ? AFR_GEMM_OUT_BF16 : 0;
@@ -512,7 +515,13 @@ extern "C" int afr_backward(afr_plan* p, void* stream) {
         const int Kz = c.max_length * c.fc_dim;
         void* z = p->ws + p->o_z;
         void* dz = p->ws + p->o_dz;
-        if ((rc = run_dw(p, s, p->layers[0], du, z, B, rt))) return rc;
+        if (stage == 0) {
+            if ((rc = run_dw(p, s, p->layers[0], du, z, B, rt))) return rc;
+            if ((rc = run_reduce_group(p, s, rt))) return rc;
+            if (g_off) *g_off = p->s_wout;
+            if (g_len) *g_len = p->total - p->s_wout;
+            return AFR_OK;
+        }
         if ((rc = run_gemm(p, s, AFR_GEMM_B_KSTRIDED | ob, du, weight_ptr(p, p->s_wout), dz, nullptr, nullptr, B, Kz, Pix, Pix,
                            Kz, Kz, 0, 1, 0))) return rc;
         SheetDims d{p->last_L, c.max_length, c.embed_dim, c.heads, c.fc_dim, c.vocab};
@@ -527,35 +536,72 @@ extern "C" int afr_backward(afr_plan* p, void* stream) {
         }
         afr_rtable_add(rt, p->G, slabs, afr_sheet_blocks(B), (long long)so.total, (long long)so.total);
         if ((rc = run_reduce_group(p, s, rt))) return rc;
-    } else {
-        const int nl = (int)p->layers.size();
-        const void* dy = du;
-        int pp = 0;
-        for (int i = nl - 1; i >= 0; --i) {
-            const auto& l = p->layers[i];
-            const void* a = p->ws + p->o_act[i];
-            if ((rc = run_dw(p, s, l, dy, a, B, rt))) return rc;
-            void* dx = p->ws + p->o_d[pp];
-            const int fl = AFR_GEMM_B_KSTRIDED | ob | (i > 0 ? AFR_GEMM_RELU_MASK : 0);
-            if ((rc = run_gemm(p, s, fl, dy, weight_ptr(p, l.w_off), dx, nullptr, i > 0 ? a : nullptr, B, l.K, l.N, l.N, l.K, l.K,
-                               l.K, 1, 0))) return rc;
-            dy = dx;
-            pp ^= 1;
-        }
-        float* slabs = (float*)(p->ws + p->o_slab_e);
-        const int blocks = afr_embed_bwd_blocks(B);
-        const long long rows = c.vocab + c.n_fonts;
-        {
-            ProfScope ps(p, s, "glyph_embed_bwd", 0.0, 0.0);
-            HIPCHK(afr_launch_glyph_embed_bwd(c.dtype, dy, p->last_x, p->last_font, B, c.embed_dim, c.vocab, c.n_fonts, slabs, s));
-        }
-        const long long stride = rows * c.embed_dim;
-        afr_rtable_add(rt, p->G + p->emb_off, slabs, blocks, stride, (long long)c.vocab * c.embed_dim);
-        if (c.n_fonts > 0)
-            afr_rtable_add(rt, p->G + p->font_off, slabs + (size_t)c.vocab * c.embed_dim, blocks, stride, (long long)c.n_fonts * c.embed_dim);
-        if ((rc = run_reduce_group(p, s, rt))) return rc;
+        if (g_off) *g_off = 0;
+        if (g_len) *g_len = p->s_wout;
+        return AFR_OK;
     }
-    p->have_du = false;
+    const int nl = (int)p->layers.size();
+    const int i = nl - 1 - stage;
+    const auto& l = p->layers[i];
+    const void* a = p->ws + p->o_act[i];
+    // d(loss)/d(output of layer i): du for the last layer, else the ping-pong buffer the previous stage wrote
+    const void* dy = stage == 0 ? du : (const void*)(p->ws + p->o_d[(stage - 1) & 1]);
+    if ((rc = run_dw(p, s, l, dy, a, B, rt))) return rc;
+    void* dx = p->ws + p->o_d[stage & 1];
+    const int fl = AFR_GEMM_B_KSTRIDED | ob | (i > 0 ? AFR_GEMM_RELU_MASK : 0);
+    if ((rc = run_gemm(p, s, fl, dy, weight_ptr(p, l.w_off), dx, nullptr, i > 0 ? a : nullptr, B, l.K, l.N, l.N, l.K, l.K,
+                       l.K, 1, 0))) return rc;
+    const int64_t end = l.b_off + (l.N + 63) / 64 * 64;
+    if (i > 0) {
+        if ((rc = run_reduce_group(p, s, rt))) return rc;
+        if (g_off) *g_off = l.w_off;
+        if (g_len) *g_len = end - l.w_off;
+        return AFR_OK;
+    }
+    float* slabs = (float*)(p->ws + p->o_slab_e);
+    const int blocks = afr_embed_bwd_blocks(B);
+    const long long rows = c.vocab + c.n_fonts;
+    {
+        ProfScope ps(p, s, "glyph_embed_bwd", 0.0, 0.0);
+        HIPCHK(afr_launch_glyph_embed_bwd(c.dtype, dx, p->last_x, p->last_font, B, c.embed_dim, c.vocab, c.n_fonts, slabs, s));
+    }
+    const long long stride = rows * c.embed_dim;
+    afr_rtable_add(rt, p->G + p->emb_off, slabs, blocks, stride, (long long)c.vocab * c.embed_dim);
+    if (c.n_fonts > 0)
+        afr_rtable_add(rt, p->G + p->font_off, slabs + (size_t)c.vocab * c.embed_dim, blocks, stride, (long long)c.n_fonts * c.embed_dim);
+    if ((rc = run_reduce_group(p, s, rt))) return rc;
+    if (g_off) *g_off = 0;
+    if (g_len) *g_len = end;
+    return AFR_OK;
+}
+
+extern "C" int afr_backward_stages(const afr_plan* p) {
+    if (!p) return 0;
+    return p->cfg.kind == AFR_KIND_SHEET ? 2 : (int)p->layers.size();
+}
+
+extern "C" int afr_backward_stage(afr_plan* p, int stage, int64_t* grad_offset, int64_t* grad_elems, void* stream) {
+    if (!p || !p->P || !p->G) return fail(AFR_ESTATE, "plan has no bound parameter/gradient buffers");
+    const int n = afr_backward_stages(p);
+    if (stage < 0 || stage >= n) return fail(AFR_EINVAL, "stage %d outside 0..%d", stage, n - 1);
+    if (stage == 0 && !p->have_du) return fail(AFR_ESTATE, "backward needs a forward + loss first");
+    if (stage != p->next_stage) return fail(AFR_ESTATE, "stages must run in order: expected %d, got %d", p->next_stage, stage);
+    int rc = backward_stage_impl(p, stage, grad_offset, grad_elems, (hipStream_t)stream);
+    if (rc) return rc;
+    p->next_stage = stage + 1 == n ? 0 : stage + 1;
+    if (stage + 1 == n) p->have_du = false;
+    return AFR_OK;
+}
+
+extern "C" int afr_backward(afr_plan* p, void* stream) {
+    if (!p || !p->P || !p->G) return fail(AFR_ESTATE, "plan has no bound parameter/gradient buffers");
+    if (!p->have_du) return fail(AFR_ESTATE, "afr_backward needs afr_forward + afr_loss_grad first");
+    p->next_stage = 0;
+    const int n = afr_backward_stages(p);
+    for (int st = 0; st < n; ++st) {
+        int rc = afr_backward_stage(p, st, nullptr, nullptr, stream);
+        if (rc) return rc;
+    }
     return AFR_OK;
 }
 
@@ -571,6 +617,15 @@ extern "C" int afr_adamw_step(afr_plan* p, float lr, float b1, float b2, float e
     ProfScope ps(p, s, "adamw", 0.0, (double)p->total * (shadow ? 30.0 : 28.0));
     HIPCHK(afr_launch_adamw(p->P, p->G, p->M, p->V, shadow, p->total, lr, b1, b2, eps, wd, bc1, bc2, gscale, s));
     return AFR_OK;
+}
+
+extern "C" int afr_forward_loss(afr_plan* p, const int64_t* x, const int64_t* font, const void* target, int tdtype, int B, int L,
+                                int64_t mean_elems, float* loss_accum, uint64_t step, void* stream) {
+    if (!target || !loss_accum) return fail(AFR_EINVAL, "target and loss_accum are required");
+    if (tdtype != AFR_TARGET_U8 && tdtype != AFR_TARGET_F32) return fail(AFR_EINVAL, "bad target dtype");
+    if (mean_elems <= 0) return fail(AFR_EINVAL, "mean_elems must be positive");
+    FusedLoss fl{target, tdtype, mean_elems, loss_accum};
+    return forward_impl(p, x, font, B, L, nullptr, 1, step, stream, &fl);
 }
 
 extern "C" int afr_train_step(afr_plan* p, const int64_t* x, const int64_t* font, const void* target, int tdtype, int B,

@@ -182,6 +182,31 @@ class Engine:
     def backward(self):
         _lib.check(self.lib.afr_backward(self._plan, _stream()))
 
+    @property
+    def backward_stages(self):
+        return int(self.lib.afr_backward_stages(self._plan))
+
+    def backward_stage(self, stage):
+        """Run one backward stage; returns the view of flat_grads that is final after it."""
+        off, n = C.c_int64(), C.c_int64()
+        _lib.check(self.lib.afr_backward_stage(self._plan, int(stage), C.byref(off), C.byref(n), _stream()))
+        return self.flat_grads[off.value:off.value + n.value]
+
+    def forward_loss(self, x, target, font=None, step=None, mean_elems=None):
+        """Training forward with the loss/grad fused into the last layer's epilogue (no optimizer step)."""
+        x, font = self._prep_x(x, font)
+        self.ensure_batch(x.shape[0])
+        t, td = self._target(target)
+        if isinstance(self.cfg, SheetConfig):
+            B, L = x.shape
+        else:
+            x = x.reshape(-1)
+            B, L = x.shape[0], 1
+        me = int(mean_elems) if mean_elems is not None else B * self.pixels
+        st = int(step if step is not None else self.t + 1)
+        _lib.check(self.lib.afr_forward_loss(self._plan, _ptr(x), _ptr(font), _ptr(t), td, B, L, me, _ptr(self.loss_accum), st, _stream()))
+        self._keep, self._keep_t = (x, font), t
+
     def adamw_step(self, lr=1e-3, betas=(0.9, 0.99), eps=1e-8, weight_decay=5e-4, grad_scale=1.0):
         self.t += 1
         _lib.check(self.lib.afr_adamw_step(self._plan, lr, betas[0], betas[1], eps, weight_decay, self.t, grad_scale, _stream()))

@@ -2,8 +2,9 @@
 
 The reference is single-device (model.py:95-106); sharding is new.  Samples are independent, so
 the batch is cut into contiguous row slices, one per rank, with NO data-path collective; the only exchange per
-step is one sum all-reduce of the flat gradient buffer (all parameters of state_dict() live in one contiguous
-float32 buffer, so it is a single RCCL call).  Every shard divides its loss by the GLOBAL element count
+step is the sum all-reduce of the flat gradient buffer (all parameters of state_dict() live in one contiguous
+float32 buffer), issued as one asynchronous RCCL call per backward stage -- last layer first -- so that it overlaps
+the rest of the backward pass.  Every shard divides its loss by the GLOBAL element count
 (`mean_elems`), so the summed gradients equal the full-batch gradients exactly, also for uneven last batches
 (192 / 304 rows in the reference's loaders).  Parameters, AdamW moments and the step counter are replicated;
 each rank draws its own dropout stream (rank is part of the counter-hash key).
@@ -30,9 +31,19 @@ class DataParallelStepper:
         if self.world == 1 or self.dist is None:
             eng.train_step(x, target, font=font, mean_elems=mean_elems, do_step=True, **hyper)
             return
-        eng.train_step(x, target, font=font, mean_elems=mean_elems, do_step=False, **hyper)
-        self.dist.all_reduce(eng.flat_grads)                  # sum over ranks; RCCL ring/tree over xGMI
-        eng.adamw_step(**{k: v for k, v in hyper.items() if k in ("lr", "betas", "eps", "weight_decay")})
+        opt = {k: v for k, v in hyper.items() if k in ("lr", "betas", "eps", "weight_decay")}
+        stages = getattr(eng, "backward_stages", 0)
+        if stages:
+            # backward runs last layer first; the sum all-reduce of each finished gradient range is issued at once
+            # (async: RCCL's stream waits for the producing kernels, the next stage's kernels do not wait for RCCL)
+            eng.forward_loss(x, target, font=font, step=hyper.get("step"), mean_elems=mean_elems)
+            works = [self.dist.all_reduce(eng.backward_stage(s), async_op=True) for s in range(stages)]
+            for w in works:
+                w.wait()
+        else:
+            eng.train_step(x, target, font=font, mean_elems=mean_elems, do_step=False, **hyper)
+            self.dist.all_reduce(eng.flat_grads)              # sum over ranks; RCCL ring/tree over xGMI
+        eng.adamw_step(**opt)
 
     def global_loss(self, reset=True):
         """Sum of the shards' loss shares == the global mean loss (each share is already / mean_elems)."""

@@ -109,6 +109,17 @@ int afr_set_output_grad(afr_plan* plan, const float* dy, int B, void* stream);
  * is implied). */
 int afr_backward(afr_plan* plan, void* stream);
 
+/* The same backward in stages (last layer first), for overlapping the gradient all-reduce with the rest of the
+ * backward pass under data parallelism: stage k leaves the flat-gradient range [*grad_offset, +*grad_elems) final.
+ * Stages must be called in order 0 .. afr_backward_stages()-1. */
+int afr_backward_stages(const afr_plan* plan);
+int afr_backward_stage(afr_plan* plan, int stage, int64_t* grad_offset, int64_t* grad_elems, void* stream);
+
+/* Training forward with the loss and d(loss)/du computed in the epilogue of the last layer (u never reaches HBM):
+ * afr_forward(training) + afr_loss_grad in one pass; follow with afr_backward / afr_backward_stage. */
+int afr_forward_loss(afr_plan* plan, const int64_t* x, const int64_t* font, const void* target, int target_dtype,
+                     int B, int L, int64_t mean_elems, float* loss_accum, uint64_t step, void* stream);
+
 /* optimizer.step(): torch.optim.AdamW as configured at model.py:273.  t = 1,2,...; grad_scale
  * multiplies every gradient first (1/world after a sum all-reduce; 1 otherwise). */
 int afr_adamw_step(afr_plan* plan, float lr, float beta1, float beta2, float eps, float weight_decay,

@@ -1,0 +1,80 @@
+"""GPU (one card): the staged backward used for all-reduce overlap equals the monolithic one bit for bit, and the
+data-parallel step path runs end to end over RCCL (backend "nccl", world size 1: the collective is an identity, the
+stream/async-handle plumbing is the real one)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from .util import GlyphConfig, glyph_inputs, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _glyph_engine(max_batch=512, dtype="f32"):
+    from ai_font_renderer_amd.engine import Engine
+    cfg = GlyphConfig(hidden=(48, 40), out_h=4, out_w=6, n_fonts=2)
+    eng = Engine(cfg, dtype=dtype, max_batch=max_batch)
+    eng.load_params(synth.make_params(cfg))
+    return cfg, eng
+
+
+@pytest.mark.parametrize("kind", ["glyph", "sheet"])
+def test_staged_backward_equals_monolithic_and_covers_the_buffer(kind):
+    from ai_font_renderer_amd.engine import Engine
+    from .util import SheetConfig
+    if kind == "glyph":
+        cfg, eng = _glyph_engine()
+        x, font, t = glyph_inputs(cfg, 300)
+        args = dict(x=torch.from_numpy(x), target=torch.from_numpy(t), font=torch.from_numpy(font))
+    else:
+        cfg = SheetConfig(max_length=24, sheet_h=16, sheet_w=40)
+        eng = Engine(cfg, max_batch=64)
+        eng.load_params(synth.make_params(cfg))
+        args = dict(x=torch.from_numpy(synth.encode_strings(synth.dataset_strings(37), 24)),
+                    target=torch.from_numpy(synth.synth_sheet_targets(37, 16, 40, tensor_id=930)), font=None)
+    eng.train_step(args["x"], args["target"], font=args["font"], step=5, do_step=False)
+    ref, lref = eng.flat_grads.clone(), eng.read_loss()
+    eng.flat_grads.fill_(float("nan"))
+    eng.forward_loss(args["x"], args["target"], font=args["font"], step=5)
+    covered = torch.zeros(eng.n_flat, dtype=torch.bool)
+    base = eng.flat_grads.data_ptr()
+    for s in range(eng.backward_stages):
+        v = eng.backward_stage(s)
+        off = (v.data_ptr() - base) // 4
+        assert not covered[off:off + v.numel()].any()
+        covered[off:off + v.numel()] = True
+        torch.cuda.synchronize()
+        for name, shape, o, n in eng.layout:                   # every tensor inside the reported range is final now
+            if off <= o and o + n <= off + v.numel():          # (alignment pads between tensors are never written)
+                assert not torch.isnan(eng.flat_grads[o:o + n]).any(), (s, name)
+    assert covered.all()
+    assert eng.read_loss() == lref
+    for name, shape, o, n in eng.layout:
+        assert torch.equal(eng.flat_grads[o:o + n], ref[o:o + n]), name
+
+
+def test_data_parallel_stepper_over_rccl_world1():
+    import torch.distributed as dist
+    from ai_font_renderer_amd.parallel import DataParallelStepper
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", str(29600 + os.getpid() % 300))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        cfg, eng = _glyph_engine()
+        x, font, t = glyph_inputs(cfg, 300)
+        xt, ft, tt = torch.from_numpy(x).cuda(), torch.from_numpy(font).cuda(), torch.from_numpy(t).cuda()
+        st = DataParallelStepper(eng, dist, world=2)          # force the multi-rank code path
+        for _ in range(3):
+            st.step(xt, tt, ft, mean_elems=300 * cfg.pixels)
+        l_dp = st.global_loss()
+        p_dp = eng.flat_params.clone()
+        cfg2, eng2 = _glyph_engine()
+        st2 = DataParallelStepper(eng2, None, 1)
+        for _ in range(3):
+            st2.step(xt, tt, ft, mean_elems=300 * cfg.pixels)
+        assert st2.global_loss() == l_dp
+        assert torch.equal(eng2.flat_params, p_dp)
+    finally:
+        dist.destroy_process_group()
