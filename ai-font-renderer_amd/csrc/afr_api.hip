@@ -330,14 +330,20 @@ extern "C" int afr_profile_dump(afr_plan* p, char* buf, int cap) {
 
 // ------------------------------------------------------------------------------------ helpers
 struct FusedLoss { const void* target; int tdtype; int64_t mean_elems; float* loss_accum; };
+struct FusedAdam { float *p, *m, *v; bf16_t* shadow; float decay, b1, b2, eps, step_size, rsqrt_bc2; };
 static inline const void* weight_ptr(const afr_plan* p, int64_t off) {
     if (p->cfg.dtype == AFR_BF16) return p->ws + p->o_shadow + (size_t)off * 2;
     return p->P + off;
 }
 static int run_gemm(afr_plan* p, hipStream_t s, int flags, const void* A, const void* B, void* C, const float* bias,
                     const void* aux, int M, int N, int K, int lda, int ldb, int ldc, int ldaux, int splitk,
-                    long long slab_stride, float* colsum = nullptr, long long colsum_stride = 0, const FusedLoss* fl = nullptr) {
+                    long long slab_stride, float* colsum = nullptr, long long colsum_stride = 0, const FusedLoss* fl = nullptr,
+                    const FusedAdam* fa = nullptr) {
     GemmParams g;
+    if (fa) {
+        g.ad_p = fa->p; g.ad_m = fa->m; g.ad_v = fa->v; g.ad_shadow = fa->shadow;
+        g.ad_decay = fa->decay; g.ad_b1 = fa->b1; g.ad_b2 = fa->b2; g.ad_eps = fa->eps; g.ad_step = fa->step_size; g.ad_rsqrt_bc2 = fa->rsqrt_bc2;
+    }
     g.colsum = colsum; g.colsum_stride = colsum_stride;
     if (fl) {
         float* scratch = (float*)(p->ws + p->o_loss);
@@ -349,7 +355,7 @@ static int run_gemm(afr_plan* p, hipStream_t s, int flags, const void* A, const 
     g.flags = flags; g.splitk = splitk; g.slab_stride = slab_stride;
     const double eb = p->cfg.dtype == AFR_BF16 ? 2.0 : 4.0;
     const double ob = (flags & AFR_GEMM_OUT_BF16) ? 2.0 : 4.0;
-    ProfScope ps(p, s, afr_gemm_kernel_name(p->cfg.dtype, flags), 2.0 * M * (double)N * K,
+    ProfScope ps(p, s, afr_gemm_kernel_name(p->cfg.dtype, g), 2.0 * M * (double)N * K,
                  eb * ((double)M * K + (double)N * K) + ob * (double)M * N * splitk);
     HIPCHK(afr_launch_gemm(p->cfg.dtype, g, s));
     return AFR_OK;
@@ -619,6 +625,54 @@ extern "C" int afr_adamw_step(afr_plan* p, float lr, float b1, float b2, float e
     return AFR_OK;
 }
 
+// Single-GPU sheet step with the optimizer fused into the weight-gradient GEMM: fc_output.weight (99.98 % of the
+// parameters) gets its AdamW update in the epilogue of dW = du^T.z, tile by tile, so its gradient is never written to
+// or re-read from HBM (-8 bytes/parameter/step) and the update traffic overlaps other tiles' MFMA work.  dz = du.W
+// runs FIRST because it must see the pre-update weights.  The small tensors take the ordinary AdamW kernel.
+static bool fused_step_eligible(const afr_plan* p, int B) {
+    return p->cfg.kind == AFR_KIND_SHEET && p->M && p->V && choose_splitk(p->layers[0].N, p->layers[0].K, B) == 1;
+}
+static int sheet_fused_step(afr_plan* p, hipStream_t s, float lr, float b1, float b2, float eps, float wd, int64_t t) {
+    const afr_config& c = p->cfg;
+    const int B = p->last_B, Pix = c.out_h * c.out_w, Kz = c.max_length * c.fc_dim;
+    const int ob = c.dtype == AFR_BF16 ? AFR_GEMM_OUT_BF16 : 0;
+    void* du = p->ws + p->o_u;
+    void* z = p->ws + p->o_z;
+    void* dz = p->ws + p->o_dz;
+    bf16_t* shadow = c.dtype == AFR_BF16 ? (bf16_t*)(p->ws + p->o_shadow) : nullptr;
+    const float bc1 = (float)(1.0 - std::pow((double)b1, (double)t));
+    const float bc2 = (float)(1.0 - std::pow((double)b2, (double)t));
+    int rc;
+    if ((rc = run_gemm(p, s, AFR_GEMM_B_KSTRIDED | ob, du, weight_ptr(p, p->s_wout), dz, nullptr, nullptr, B, Kz, Pix, Pix,
+                       Kz, Kz, 0, 1, 0))) return rc;
+    FusedAdam fa{p->P + p->s_wout, p->M + p->s_wout, p->V + p->s_wout, shadow ? shadow + p->s_wout : nullptr,
+                 1.f - lr * wd, b1, b2, eps, lr / bc1, (float)(1.0 / std::sqrt((double)bc2))};
+    if ((rc = run_gemm(p, s, AFR_GEMM_A_KSTRIDED | AFR_GEMM_B_KSTRIDED, du, z, p->G + p->s_wout, nullptr, nullptr, Pix, Kz, B, Pix, Kz,
+                       Kz, 0, 1, 0, p->G + p->s_bout, 0, nullptr, &fa))) return rc;
+    SheetDims d{p->last_L, c.max_length, c.embed_dim, c.heads, c.fc_dim, c.vocab};
+    float* slabs = (float*)(p->ws + p->o_slab_e);
+    SheetSlabOff so{(int)p->s_pos, (int)p->s_emb, (int)p->s_win, (int)p->s_bin, (int)p->s_wo, (int)p->s_bo, (int)p->s_g,
+                    (int)p->s_b, (int)p->s_w1, (int)p->s_b1, (int)p->s_wout};
+    {
+        ProfScope ps(p, s, "sheet_bwd", 0.0, 0.0);
+        HIPCHK(afr_launch_sheet_bwd(c.dtype, d, sheet_params(p), make_drop(p, p->last_training, p->last_step), p->last_x,
+                                    p->last_ldx, B, dz, c.ln_eps, slabs, so, s));
+    }
+    RTable rt;
+    rt.nseg = 0; rt.nblocks = 0;
+    afr_rtable_add(rt, p->G, slabs, afr_sheet_blocks(B), (long long)so.total, (long long)so.total);
+    if ((rc = run_reduce_group(p, s, rt))) return rc;
+    {   // the ten small tensors, then fc_output.bias
+        ProfScope ps(p, s, "adamw", 0.0, (double)(p->total - (p->s_bout - p->s_wout)) * 28.0);
+        HIPCHK(afr_launch_adamw(p->P, p->G, p->M, p->V, shadow, p->s_wout, lr, b1, b2, eps, wd, bc1, bc2, 1.f, s));
+        HIPCHK(afr_launch_adamw(p->P + p->s_bout, p->G + p->s_bout, p->M + p->s_bout, p->V + p->s_bout,
+                                shadow ? shadow + p->s_bout : nullptr, p->total - p->s_bout, lr, b1, b2, eps, wd, bc1, bc2, 1.f, s));
+    }
+    p->have_du = false;
+    p->next_stage = 0;
+    return AFR_OK;
+}
+
 extern "C" int afr_forward_loss(afr_plan* p, const int64_t* x, const int64_t* font, const void* target, int tdtype, int B, int L,
                                 int64_t mean_elems, float* loss_accum, uint64_t step, void* stream) {
     if (!target || !loss_accum) return fail(AFR_EINVAL, "target and loss_accum are required");
@@ -638,6 +692,10 @@ extern "C" int afr_train_step(afr_plan* p, const int64_t* x, const int64_t* font
     // the loss and its gradient are computed in the epilogue of the last forward GEMM: u never touches HBM
     FusedLoss fl{target, tdtype, mean_elems, loss_accum};
     if ((rc = forward_impl(p, x, font, B, L, nullptr, 1, step, stream, &fl))) return rc;
+    if (do_step && fused_step_eligible(p, B) && !(p->cfg.reserved & 1)) {
+        if (t < 1) return fail(AFR_EINVAL, "t starts at 1");
+        return sheet_fused_step(p, (hipStream_t)stream, lr, b1, b2, eps, wd, t);
+    }
     if ((rc = afr_backward(p, stream))) return rc;
     if (do_step && (rc = afr_adamw_step(p, lr, b1, b2, eps, wd, t, 1.f, stream))) return rc;
     return AFR_OK;

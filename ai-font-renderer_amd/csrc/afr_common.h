@@ -109,9 +109,22 @@ struct GemmParams {
     float* mse_partial = nullptr;       // per-block partial sums (>= grid floats)
     unsigned* mse_counter = nullptr;    // arrival counter, zero on entry, re-armed by the last block
     float* mse_loss_accum = nullptr;    // device scalar: += sum(partials) / mean_elems
+    // optional fused optimizer (dW GEMMs only, single GPU): C is the weight's gradient tile; instead of storing it
+    // the epilogue applies AdamW to the matching tile of p/m/v (same [M][ldc] layout) and refreshes the bf16 shadow
+    float* ad_p = nullptr; float* ad_m = nullptr; float* ad_v = nullptr; bf16_t* ad_shadow = nullptr;
+    float ad_decay = 1.f, ad_b1 = 0.f, ad_b2 = 0.f, ad_eps = 0.f, ad_step = 0.f, ad_rsqrt_bc2 = 1.f;
 };
+// torch.optim.AdamW element update (reference model.py:273,310); shared by adamw_kernel and the fused GEMM epilogue
+__device__ __forceinline__ void adamw_elem(float& p, float& m, float& v, float g, float decay, float b1, float b2,
+                                           float eps, float step_size, float rsqrt_bc2) {
+    p *= decay;
+    m = m + (g - m) * (1.f - b1);
+    v = v * b2 + (1.f - b2) * g * g;
+    const float denom = sqrtf(v) * rsqrt_bc2 + eps;
+    p -= step_size * (m / denom);
+}
 hipError_t afr_launch_gemm(int dtype, const GemmParams& p, hipStream_t s);
-const char* afr_gemm_kernel_name(int dtype, int flags);
+const char* afr_gemm_kernel_name(int dtype, const GemmParams& p);
 
 hipError_t afr_launch_reduce(float* dst, const float* slabs, int nslabs, long long slab_stride, long long n,
                              float scale, int accumulate, hipStream_t s);

@@ -90,7 +90,6 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
                                                     float b2, float eps, float wd, float step_size, float rsqrt_bc2,
                                                     float gscale) {
     const float decay = 1.f - lr * wd;
-    const float omb1 = 1.f - b1, omb2 = 1.f - b2;
     for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
         float4 pp = reinterpret_cast<float4*>(p)[i];
         float4 gg = reinterpret_cast<const float4*>(g)[i];
@@ -99,14 +98,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
         float pa[4] = {pp.x, pp.y, pp.z, pp.w}, ga[4] = {gg.x, gg.y, gg.z, gg.w};
         float ma[4] = {mm.x, mm.y, mm.z, mm.w}, va[4] = {vv.x, vv.y, vv.z, vv.w};
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const float gk = ga[k] * gscale;
-            pa[k] *= decay;
-            ma[k] = ma[k] + (gk - ma[k]) * omb1;
-            va[k] = va[k] * b2 + omb2 * gk * gk;
-            const float denom = sqrtf(va[k]) * rsqrt_bc2 + eps;
-            pa[k] -= step_size * (ma[k] / denom);
-        }
+        for (int k = 0; k < 4; ++k) adamw_elem(pa[k], ma[k], va[k], ga[k] * gscale, decay, b1, b2, eps, step_size, rsqrt_bc2);
         reinterpret_cast<float4*>(p)[i] = make_float4(pa[0], pa[1], pa[2], pa[3]);
         reinterpret_cast<float4*>(m)[i] = make_float4(ma[0], ma[1], ma[2], ma[3]);
         reinterpret_cast<float4*>(v)[i] = make_float4(va[0], va[1], va[2], va[3]);

@@ -55,7 +55,9 @@ typedef struct afr_config {
     /* dropout stream */
     uint64_t seed;
     int32_t rank;        /* data-parallel rank: gives each replica its own dropout stream         */
-    int32_t reserved;
+    int32_t reserved;    /* bit 0: keep the optimizer un-fused in afr_train_step (gradients of every tensor are
+                            then materialised; otherwise the sheet model's fc_output.weight is updated inside its
+                            weight-gradient GEMM and its gradient never reaches HBM)                              */
 } afr_config;
 
 typedef struct afr_plan afr_plan;
@@ -126,7 +128,8 @@ int afr_adamw_step(afr_plan* plan, float lr, float beta1, float beta2, float eps
                    int64_t t, float grad_scale, void* stream);
 
 /* One whole iteration of the loop body model.py:292-310 on this rank's shard:
- * forward(training) -> loss+grad -> backward [-> AdamW when do_step!=0]. */
+ * forward(training) -> loss+grad -> backward [-> AdamW when do_step!=0].  With do_step!=0 the loss is fused into
+ * the last forward GEMM and, for the sheet model, the AdamW update of fc_output.weight into its dW GEMM. */
 int afr_train_step(afr_plan* plan, const int64_t* x, const int64_t* font, const void* target,
                    int target_dtype, int B, int L, int64_t mean_elems, float* loss_accum,
                    uint64_t step, int do_step, float lr, float beta1, float beta2, float eps,
