@@ -49,10 +49,9 @@ struct afr_plan {
     char* ws = nullptr;
     size_t ws_bytes = 0, ws_need = 0;
     // workspace offsets (bytes)
-    size_t o_shadow = 0, o_err = 0, o_loss = 0, o_u = 0, o_z = 0, o_dz = 0, o_slab_w = 0, o_slab_c = 0, o_slab_e = 0;
+    size_t o_shadow = 0, o_err = 0, o_loss = 0, o_u = 0, o_z = 0, o_dz = 0, o_slab_e = 0;
     std::vector<size_t> o_act;     // glyph: activations h0..h_nh
     size_t o_d[2] = {0, 0};        // glyph: ping-pong d buffers
-    size_t slab_w_elems = 0;
     // glyph layer table
     struct Layer { int N, K; int64_t w_off, b_off; int sk = 1; size_t o_slab_w = 0, o_slab_b = 0; };
     std::vector<Layer> layers;
@@ -433,7 +432,7 @@ static int forward_impl(afr_plan* p, const int64_t* x, const int64_t* font, int 
         SheetDims d{Lc, c.max_length, c.embed_dim, c.heads, c.fc_dim, c.vocab};
         void* z = p->ws + p->o_z;
         {
-            ProfScope ps(p, s, "sheet_fwd", 0.0, 0.0);
+            ProfScope ps(p, s, "sheet_fwd", 2.5e6 * B, 0.0);        // ~2.5 MFLOP of f32 VALU work per string
             HIPCHK(afr_launch_sheet_fwd(c.dtype, d, sheet_params(p), make_drop(p, training, step), x, L, B, z, c.ln_eps, err, s));
         }
         const int Kz = c.max_length * c.fc_dim;
@@ -536,7 +535,7 @@ static int backward_stage_impl(afr_plan* p, int stage, int64_t* g_off, int64_t* 
         SheetSlabOff so{(int)p->s_pos, (int)p->s_emb, (int)p->s_win, (int)p->s_bin, (int)p->s_wo, (int)p->s_bo, (int)p->s_g,
                         (int)p->s_b, (int)p->s_w1, (int)p->s_b1, (int)p->s_wout};
         {
-            ProfScope ps(p, s, "sheet_bwd", 0.0, 0.0);
+            ProfScope ps(p, s, "sheet_bwd", 9.0e6 * B, 0.0);       // recompute + reverse: ~9 MFLOP of f32 VALU work per string
             HIPCHK(afr_launch_sheet_bwd(c.dtype, d, sheet_params(p), make_drop(p, p->last_training, p->last_step), p->last_x,
                                         p->last_ldx, B, dz, c.ln_eps, slabs, so, s));
         }
@@ -654,7 +653,7 @@ static int sheet_fused_step(afr_plan* p, hipStream_t s, float lr, float b1, floa
     SheetSlabOff so{(int)p->s_pos, (int)p->s_emb, (int)p->s_win, (int)p->s_bin, (int)p->s_wo, (int)p->s_bo, (int)p->s_g,
                     (int)p->s_b, (int)p->s_w1, (int)p->s_b1, (int)p->s_wout};
     {
-        ProfScope ps(p, s, "sheet_bwd", 0.0, 0.0);
+        ProfScope ps(p, s, "sheet_bwd", 9.0e6 * B, 0.0);
         HIPCHK(afr_launch_sheet_bwd(c.dtype, d, sheet_params(p), make_drop(p, p->last_training, p->last_step), p->last_x,
                                     p->last_ldx, B, dz, c.ln_eps, slabs, so, s));
     }

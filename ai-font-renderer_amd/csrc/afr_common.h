@@ -146,10 +146,6 @@ hipError_t afr_launch_mse_grad(int act_dtype, const void* u, const void* target,
 hipError_t afr_launch_f32_to_bf16(const float* src, bf16_t* dst, long long n, hipStream_t s);
 hipError_t afr_launch_clamp_bwd(int act_dtype, void* u_inout, const float* dy, long long n, hipStream_t s);
 hipError_t afr_launch_clamp_out(int act_dtype, const void* u, float* y, long long n, hipStream_t s);
-// column sums of X[rows][cols] (act dtype) -> slabs[nsplit][cols] (f32); returns nsplit via out param
-int afr_colsum_splits(long long rows);
-hipError_t afr_launch_colsum(int act_dtype, const void* X, long long rows, long long cols, long long ld,
-                             float* slabs, hipStream_t s);
 // glyph embedding gather / deterministic scatter-add
 hipError_t afr_launch_glyph_embed(int act_dtype, const float* emb, const float* font_emb, const int64_t* x,
                                   const int64_t* font, int B, int E, int vocab, int n_fonts, void* out,

@@ -1,5 +1,5 @@
 // elementwise.hip -- the HBM-bound kernels of the hot path: loss/grad reduction, AdamW, slab reduction,
-// column sums (bias gradients), the glyph embedding gather and its deterministic scatter-add.
+// the glyph embedding gather and its deterministic scatter-add (bias gradients are fused into the dW GEMM).
 // All are 16-byte-per-lane streaming kernels with grid-stride loops; reductions are shuffle -> LDS ->
 // per-block partial -> fixed-order finish, so every result is bitwise reproducible run to run.
 #include "afr_common.h"
@@ -245,40 +245,6 @@ hipError_t afr_launch_mse_grad(int act_dtype, const void* u, const void* target,
         if (target_dtype == AFR_TARGET_U8) MSE(float, uint8_t); else MSE(float, float);
     }
 #undef MSE
-    return hipGetLastError();
-}
-
-// -------------------------------------------------------------------------------- column sums
-// slabs[sp][c] = sum over the sp-th slice of rows of X[r][c]: the bias gradients db = sum_b dy (model.py:309).
-// Lane owns 4 consecutive columns (16 B f32 / 8 B bf16), rows split over blockIdx.y.
-constexpr int COLSUM_ROWS = 128;
-template <typename T>
-__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ X, long long rows, long long cols, long long ld,
-                                                     float* __restrict__ slabs) {
-    const long long c = (blockIdx.x * 256ll + threadIdx.x) * 4;
-    if (c >= cols) return;
-    const long long r0 = (long long)blockIdx.y * COLSUM_ROWS;
-    const long long r1 = min(rows, r0 + COLSUM_ROWS);
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    for (long long r = r0; r < r1; ++r) {
-        if (sizeof(T) == 4) {
-            const float4 v = *reinterpret_cast<const float4*>(X + r * ld + c);
-            a0 += v.x; a1 += v.y; a2 += v.z; a3 += v.w;
-        } else {
-            const bf16x4 v = *reinterpret_cast<const bf16x4*>(X + r * ld + c);
-            a0 += (float)v[0]; a1 += (float)v[1]; a2 += (float)v[2]; a3 += (float)v[3];
-        }
-    }
-    *reinterpret_cast<float4*>(slabs + (long long)blockIdx.y * cols + c) = make_float4(a0, a1, a2, a3);
-}
-int afr_colsum_splits(long long rows) { return (int)((rows + COLSUM_ROWS - 1) / COLSUM_ROWS); }
-hipError_t afr_launch_colsum(int act_dtype, const void* X, long long rows, long long cols, long long ld, float* slabs,
-                             hipStream_t s) {
-    if (rows <= 0 || cols <= 0) return hipSuccess;
-    if (cols & 3) return hipErrorInvalidValue;
-    dim3 g((unsigned)((cols / 4 + 255) / 256), (unsigned)afr_colsum_splits(rows)), b(256);
-    if (act_dtype == AFR_BF16) hipLaunchKernelGGL(colsum_kernel<bf16_t>, g, b, 0, s, (const bf16_t*)X, rows, cols, ld, slabs);
-    else hipLaunchKernelGGL(colsum_kernel<float>, g, b, 0, s, (const float*)X, rows, cols, ld, slabs);
     return hipGetLastError();
 }
 

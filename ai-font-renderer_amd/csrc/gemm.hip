@@ -373,7 +373,10 @@ __global__ __launch_bounds__(128 * WM, 2) void gemm_bf16(GemmParams p) {
 #pragma unroll
         for (int t = 0; t < 3; ++t)
             if (t < nt) stage(t, t);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // start as soon as tile 0 has landed: tiles 1 and 2 (the newest 2 x 6 wave-instructions) stay in flight
+        if (nt >= 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        else if (nt == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         bf16x8 a0[4], b0[4], a1[4], b1[4];
         if (nt > 0) { read_a(smem, 0, a0); read_b(smem, 0, b0); }

@@ -178,8 +178,9 @@ def main():
         value = world * B * K / elapsed
         if dom["algo_flops"] > 0:
             ach = dom["algo_flops"] / (dom["avg_ms"] * 1e-3) / 1e12
-            roof = {"bound": "mfma", "kernel": dom["kernel"], "achieved": ach, "peak": PEAK[dtype], "unit": "TFLOP/s",
-                    "frac": ach / PEAK[dtype], "traffic": None, "avg_launch_ms": dom["avg_ms"], "launches": dom["launches"],
+            peak = PEAK["f32"] if dom["kernel"].startswith(("sheet_", "gemm_f32")) else PEAK[dtype]   # f32 VALU peak == f32 MFMA peak
+            roof = {"bound": "mfma" if dom["kernel"].startswith("gemm") else "valu", "kernel": dom["kernel"], "achieved": ach,
+                    "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None, "avg_launch_ms": dom["avg_ms"], "launches": dom["launches"],
                     "algo_flops_per_launch": dom["algo_flops"]}
         else:
             ach = dom["algo_bytes"] / (dom["avg_ms"] * 1e-3) / 1e9
