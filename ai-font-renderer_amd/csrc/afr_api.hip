@@ -354,8 +354,10 @@ static int run_gemm(afr_plan* p, hipStream_t s, int flags, const void* A, const 
     g.flags = flags; g.splitk = splitk; g.slab_stride = slab_stride;
     const double eb = p->cfg.dtype == AFR_BF16 ? 2.0 : 4.0;
     const double ob = (flags & AFR_GEMM_OUT_BF16) ? 2.0 : 4.0;
+    // algorithmic bytes: operands once + output once; with the fused optimizer the output is p,m,v read + p,m,v(,shadow) written
+    const double out_bytes = fa ? (double)M * N * (24.0 + (fa->shadow ? 2.0 : 0.0)) : ob * (double)M * N * splitk;
     ProfScope ps(p, s, afr_gemm_kernel_name(p->cfg.dtype, g), 2.0 * M * (double)N * K,
-                 eb * ((double)M * K + (double)N * K) + ob * (double)M * N * splitk);
+                 eb * ((double)M * K + (double)N * K) + out_bytes);
     HIPCHK(afr_launch_gemm(p->cfg.dtype, g, s));
     return AFR_OK;
 }

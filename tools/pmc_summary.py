@@ -1,13 +1,52 @@
-import csv, glob, sys, collections
+#!/usr/bin/env python3
+"""Summarise rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (collected separately, as the microarch guide prescribes)
+into per-kernel HBM traffic per launch.  FETCH_SIZE is doubled (gfx950 reports half the bytes of 16-B/lane streams).
+
+  python tools/pmc_summary.py <dir prefix> <workload> [...] [--json out.json]
+expects <prefix>_<workload>_FETCH_SIZE/ and <prefix>_<workload>_WRITE_SIZE/ (rocprofv3 -d outputs, csv)."""
+import collections
+import csv
+import glob
+import json
+import re
+import sys
+
+
 def load(d):
-    f = glob.glob(d + '/runc/*_counter_collection.csv')[0]
+    f = glob.glob(d + "/*/*_counter_collection.csv")[0]
     acc = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
-        acc[r['Kernel_Name']].append(float(r['Counter_Value']))
+        acc[r["Kernel_Name"]].append(float(r["Counter_Value"]))
     return acc
-for tag in sys.argv[1:]:
-    fe, wr = load(f'pmc_{tag}_FETCH_SIZE'), load(f'pmc_{tag}_WRITE_SIZE')
-    print(f'== {tag}: per-launch averages (KB as reported; FETCH x2 corrected for 16B/lane streaming reads)')
-    for k in sorted(fe, key=lambda k: -sum(fe[k])):
-        f = sum(fe[k]) / len(fe[k]); w = sum(wr.get(k, [0])) / max(1, len(wr.get(k, [0])))
-        print(f'{k[:60]:60s} n={len(fe[k]):4d} FETCH={f/1024:9.2f} MB (x2={2*f/1024:9.2f}) WRITE={w/1024:9.2f} MB')
+
+
+def short(name):
+    m = re.search(r"(gemm_(?:bf16|f32)<[^>]*>)", name)
+    if m:
+        return m.group(1).replace(" ", "")
+    for k in ("sheet_bwd", "sheet_fwd", "adamw", "reduce_group", "mse_grad", "glyph_embed_bwd", "glyph_embed", "f32_to_bf16"):
+        if k in name:
+            return k
+    return name[:40]
+
+
+def main():
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    out_json = sys.argv[sys.argv.index("--json") + 1] if "--json" in sys.argv else None
+    prefix, workloads = args[0], [a for a in args[1:] if a != out_json]
+    result = {}
+    for w in workloads:
+        fe, wr = load(f"{prefix}_{w}_FETCH_SIZE"), load(f"{prefix}_{w}_WRITE_SIZE")
+        print(f"== {w}: HBM traffic per launch (KB counters -> MB; FETCH x2 corrected)")
+        result[w] = {}
+        for k in sorted(fe, key=lambda k: -sum(fe[k])):
+            f = 2.0 * sum(fe[k]) / len(fe[k]) * 1024.0
+            ww = sum(wr.get(k, [0])) / max(1, len(wr.get(k, [0]))) * 1024.0
+            print(f"{short(k):22s} n={len(fe[k]):4d} read={f / 1e6:10.2f} MB  write={ww / 1e6:10.2f} MB  total={(f + ww) / 1e6:10.2f} MB")
+            result[w][short(k)] = {"read_bytes": f, "write_bytes": ww, "launches": len(fe[k])}
+    if out_json:
+        json.dump(result, open(out_json, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
