@@ -93,9 +93,12 @@ static int64_t off_of(const afr_plan* p, const char* name) {
     return -1;
 }
 
+#ifndef AFR_SPLITK_TARGET
+#define AFR_SPLITK_TARGET 512
+#endif
 static int choose_splitk(int M, int N, int K) {
     const int tiles = ((M + 127) / 128) * ((N + 127) / 128);
-    int s = (512 + tiles - 1) / tiles;
+    int s = (AFR_SPLITK_TARGET + tiles - 1) / tiles;
     const int maxs = K / 256 > 0 ? K / 256 : 1;
     if (s > maxs) s = maxs;
     if (s < 1) s = 1;
@@ -510,21 +513,25 @@ extern "C" int afr_set_output_grad(afr_plan* p, const float* dy, int B, void* st
 // (its own slab reduction included), so a data-parallel caller can start the all-reduce of that range while the
 // next stage computes.  Glyph: one stage per Linear (the first layer's stage also does the embedding tables).
 // Sheet: stage 0 = fc_output (dW + db), stage 1 = dz GEMM + fused front-end backward.
-static int backward_stage_impl(afr_plan* p, int stage, int64_t* g_off, int64_t* g_len, hipStream_t s) {
+static int backward_stage_impl(afr_plan* p, int stage, int64_t* g_off, int64_t* g_len, hipStream_t s, RTable* shared_rt) {
     const afr_config& c = p->cfg;
     const int B = p->last_B, Pix = c.out_h * c.out_w;
     const int ob = c.dtype == AFR_BF16 ? AFR_GEMM_OUT_BF16 : 0;
     void* du = p->ws + p->o_u;
     int rc;
-    RTable rt;
-    rt.nseg = 0; rt.nblocks = 0;
+    // slab reductions: flushed per stage (so the stage's gradient range is final), or deferred to ONE grouped launch
+    // at the end of a monolithic afr_backward (shared_rt)
+    RTable local_rt;
+    local_rt.nseg = 0; local_rt.nblocks = 0;
+    RTable& rt = shared_rt ? *shared_rt : local_rt;
+    auto flush = [&]() -> int { return shared_rt ? AFR_OK : run_reduce_group(p, s, rt); };
     if (c.kind == AFR_KIND_SHEET) {
         const int Kz = c.max_length * c.fc_dim;
         void* z = p->ws + p->o_z;
         void* dz = p->ws + p->o_dz;
         if (stage == 0) {
             if ((rc = run_dw(p, s, p->layers[0], du, z, B, rt))) return rc;
-            if ((rc = run_reduce_group(p, s, rt))) return rc;
+            if ((rc = flush())) return rc;
             if (g_off) *g_off = p->s_wout;
             if (g_len) *g_len = p->total - p->s_wout;
             return AFR_OK;
@@ -542,7 +549,7 @@ static int backward_stage_impl(afr_plan* p, int stage, int64_t* g_off, int64_t* 
                                         p->last_ldx, B, dz, c.ln_eps, slabs, so, s));
         }
         afr_rtable_add(rt, p->G, slabs, afr_sheet_blocks(B), (long long)so.total, (long long)so.total);
-        if ((rc = run_reduce_group(p, s, rt))) return rc;
+        if ((rc = flush())) return rc;
         if (g_off) *g_off = 0;
         if (g_len) *g_len = p->s_wout;
         return AFR_OK;
@@ -560,7 +567,7 @@ static int backward_stage_impl(afr_plan* p, int stage, int64_t* g_off, int64_t* 
                        l.K, 1, 0))) return rc;
     const int64_t end = l.b_off + (l.N + 63) / 64 * 64;
     if (i > 0) {
-        if ((rc = run_reduce_group(p, s, rt))) return rc;
+        if ((rc = flush())) return rc;
         if (g_off) *g_off = l.w_off;
         if (g_len) *g_len = end - l.w_off;
         return AFR_OK;
@@ -576,7 +583,7 @@ static int backward_stage_impl(afr_plan* p, int stage, int64_t* g_off, int64_t* 
     afr_rtable_add(rt, p->G + p->emb_off, slabs, blocks, stride, (long long)c.vocab * c.embed_dim);
     if (c.n_fonts > 0)
         afr_rtable_add(rt, p->G + p->font_off, slabs + (size_t)c.vocab * c.embed_dim, blocks, stride, (long long)c.n_fonts * c.embed_dim);
-    if ((rc = run_reduce_group(p, s, rt))) return rc;
+    if ((rc = flush())) return rc;
     if (g_off) *g_off = 0;
     if (g_len) *g_len = end;
     return AFR_OK;
@@ -593,7 +600,7 @@ extern "C" int afr_backward_stage(afr_plan* p, int stage, int64_t* grad_offset, 
     if (stage < 0 || stage >= n) return fail(AFR_EINVAL, "stage %d outside 0..%d", stage, n - 1);
     if (stage == 0 && !p->have_du) return fail(AFR_ESTATE, "backward needs a forward + loss first");
     if (stage != p->next_stage) return fail(AFR_ESTATE, "stages must run in order: expected %d, got %d", p->next_stage, stage);
-    int rc = backward_stage_impl(p, stage, grad_offset, grad_elems, (hipStream_t)stream);
+    int rc = backward_stage_impl(p, stage, grad_offset, grad_elems, (hipStream_t)stream, nullptr);
     if (rc) return rc;
     p->next_stage = stage + 1 == n ? 0 : stage + 1;
     if (stage + 1 == n) p->have_du = false;
@@ -603,12 +610,17 @@ extern "C" int afr_backward_stage(afr_plan* p, int stage, int64_t* grad_offset, 
 extern "C" int afr_backward(afr_plan* p, void* stream) {
     if (!p || !p->P || !p->G) return fail(AFR_ESTATE, "plan has no bound parameter/gradient buffers");
     if (!p->have_du) return fail(AFR_ESTATE, "afr_backward needs afr_forward + afr_loss_grad first");
-    p->next_stage = 0;
     const int n = afr_backward_stages(p);
+    RTable rt;
+    rt.nseg = 0; rt.nblocks = 0;
     for (int st = 0; st < n; ++st) {
-        int rc = afr_backward_stage(p, st, nullptr, nullptr, stream);
+        int rc = backward_stage_impl(p, st, nullptr, nullptr, (hipStream_t)stream, &rt);
         if (rc) return rc;
     }
+    int rc = run_reduce_group(p, (hipStream_t)stream, rt);
+    if (rc) return rc;
+    p->next_stage = 0;
+    p->have_du = false;
     return AFR_OK;
 }
 

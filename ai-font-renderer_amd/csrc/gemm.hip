@@ -307,7 +307,6 @@ __global__ __launch_bounds__(128 * WM, 2) void gemm_bf16(GemmParams p) {
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const bool do_cs = (ALAY == 1) && p.colsum != nullptr && tn == 0;   // fused bias gradient: column sums of A tiles
-    float cs = 0.f;
     const int nt = (kend > kbeg) ? (kend - kbeg + BK - 1) / BK : 0;
     const i32x4 rA = make_rsrc(A), rB = make_rsrc(B);
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
@@ -351,14 +350,22 @@ __global__ __launch_bounds__(128 * WM, 2) void gemm_bf16(GemmParams p) {
         for (int i = 0; i < 4; ++i) { asm volatile("" ::"v"(fa[i])); asm volatile("" ::"v"(fb[i])); }
 #endif
     };
+    // fused bias gradient: column sums of the k-strided A tile [64 k][BM x].  A thread owns one 16-byte chunk (8
+    // consecutive x) and walks 4 of the 64 k-rows; 16 threads share a chunk and are combined once after the K loop.
+    constexpr int CH = BM / 8;                       // chunks per k-row; NTHR / CH == 16 row groups
+    float cs8[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) cs8[r] = 0.f;
     auto colsum_tile = [&](const char* S) {
-        const int xx = tid % BM, hf = tid / BM;
-        const char* Ac = S + (xx >> 7) * SUB;
-        const int xl = xx & 127;
-#pragma unroll 8
-        for (int kk = 0; kk < BK / 2; ++kk) {
-            const int k = hf * (BK / 2) + kk;
-            cs += (float)*reinterpret_cast<const bf16_t*>(Ac + k * 256 + (((xl >> 4) ^ fswz(k)) << 5) + (xl & 15) * 2);
+        const int c = tid % CH, rg = tid / CH;
+        const char* Ac = S + (c >> 4) * SUB;
+        const int cl = c & 15;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int k = rg + 16 * i;
+            const bf16x8 v = *reinterpret_cast<const bf16x8*>(Ac + k * 256 + ((cl ^ (fswz(k) << 1)) << 4));
+#pragma unroll
+            for (int r = 0; r < 8; ++r) cs8[r] += (float)v[r];
         }
     };
 
@@ -427,10 +434,17 @@ __global__ __launch_bounds__(128 * WM, 2) void gemm_bf16(GemmParams p) {
     }
 
     if (ALAY == 1 && do_cs) {
-        float* red = reinterpret_cast<float*>(smem);
-        red[tid] = cs;
+        float* red = reinterpret_cast<float*>(smem);           // [16 row groups][BM]
+        const int c = tid % CH, rg = tid / CH;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) red[rg * BM + 8 * c + r] = cs8[r];
         __syncthreads();
-        if (tid < BM && m0 + tid < p.M) p.colsum[(size_t)z * p.colsum_stride + m0 + tid] = red[tid] + red[tid + BM];
+        if (tid < BM && m0 + tid < p.M) {
+            float a = 0.f;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) a += red[g * BM + tid];
+            p.colsum[(size_t)z * p.colsum_stride + m0 + tid] = a;
+        }
         __syncthreads();                       // the staging below reuses this LDS
     }
     // Epilogue through LDS: the MFMA accumulators hold 4 consecutive n of 16 different rows per lane-group, which as
@@ -465,24 +479,54 @@ __global__ __launch_bounds__(128 * WM, 2) void gemm_bf16(GemmParams p) {
     const bf16_t* aux = reinterpret_cast<const bf16_t*>(p.aux);
     float lsum = 0.f;
     const float g2 = 2.f * p.mse_inv_n;
+    const int c8 = lane & 7;
+    const int n = n0 + wn * 64 + 8 * c8;
+    const bool ncol = n < p.N;
+    const bool relu_mask = flags & AFR_GEMM_RELU_MASK;
+    // the tails' global operands (aux for the ReLU mask, targets for the fused loss) are fetched for all 8 row passes
+    // up front: one memory latency instead of eight serial ones
+    bf16x8 auxv[8];
+    uint2 tu8[8];
+    if (relu_mask || (mse && p.mse_target_dtype == AFR_TARGET_U8)) {
+#pragma unroll
+        for (int ps = 0; ps < 8; ++ps) {
+            const int m = m0 + wm * 64 + ps * 8 + (lane >> 3);
+            if (m < p.M && ncol) {
+                if (relu_mask) auxv[ps] = *reinterpret_cast<const bf16x8*>(aux + (size_t)m * p.ldaux + n);
+                if (mse) tu8[ps] = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint8_t*>(p.mse_target) + (size_t)m * p.N + n);
+            }
+        }
+    }
+    // fused AdamW operands are double-buffered one pass ahead (6 x 16 B per pass)
+    float4 adp[2][2], adm[2][2], adv[2][2];
+    auto load_adam = [&](int ps, int buf) {
+        const int m = m0 + wm * 64 + ps * 8 + (lane >> 3);
+        if (m < p.M && ncol) {
+            const size_t wi = (size_t)m * p.ldc + n;
+            adp[buf][0] = *reinterpret_cast<const float4*>(p.ad_p + wi); adp[buf][1] = *reinterpret_cast<const float4*>(p.ad_p + wi + 4);
+            adm[buf][0] = *reinterpret_cast<const float4*>(p.ad_m + wi); adm[buf][1] = *reinterpret_cast<const float4*>(p.ad_m + wi + 4);
+            adv[buf][0] = *reinterpret_cast<const float4*>(p.ad_v + wi); adv[buf][1] = *reinterpret_cast<const float4*>(p.ad_v + wi + 4);
+        }
+    };
+    if (p.ad_p) load_adam(0, 0);
 #pragma unroll
     for (int ps = 0; ps < 8; ++ps) {
-        const int rl = ps * 8 + (lane >> 3), c8 = lane & 7;
+        const int rl = ps * 8 + (lane >> 3);
+        if (p.ad_p && ps + 1 < 8) load_adam(ps + 1, (ps + 1) & 1);
         const f32x4 lo = *reinterpret_cast<const f32x4*>(Wt + rl * 64 + (((2 * c8) ^ (rl & 15)) << 2));
         const f32x4 hi = *reinterpret_cast<const f32x4*>(Wt + rl * 64 + (((2 * c8 + 1) ^ (rl & 15)) << 2));
         float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        const int m = m0 + wm * 64 + rl, n = n0 + wn * 64 + 8 * c8;
-        if (m >= p.M || n >= p.N) continue;
-        if (flags & AFR_GEMM_RELU_MASK) {
-            const bf16x8 a = *reinterpret_cast<const bf16x8*>(aux + (size_t)m * p.ldaux + n);
+        const int m = m0 + wm * 64 + rl;
+        if (m >= p.M || !ncol) continue;
+        if (relu_mask) {
 #pragma unroll
-            for (int r = 0; r < 8; ++r) v[r] = ((float)a[r] > 0.f) ? v[r] : 0.f;
+            for (int r = 0; r < 8; ++r) v[r] = ((float)auxv[ps][r] > 0.f) ? v[r] : 0.f;
         }
         if (mse) {
             float t[8];
             const size_t ti = (size_t)m * p.N + n;
             if (p.mse_target_dtype == AFR_TARGET_U8) {
-                const uint2 w = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint8_t*>(p.mse_target) + ti);
+                const uint2 w = tu8[ps];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { t[r] = (float)((w.x >> (8 * r)) & 0xFF) / 255.0f; t[4 + r] = (float)((w.y >> (8 * r)) & 0xFF) / 255.0f; }
             } else {
@@ -500,21 +544,18 @@ __global__ __launch_bounds__(128 * WM, 2) void gemm_bf16(GemmParams p) {
         }
         if (p.ad_p) {                                  // fused AdamW: v[] is the gradient of weight elements (m, n..n+7)
             const size_t wi = (size_t)m * p.ldc + n;
-            float pp[8], mm[8], vv[8];
-            *reinterpret_cast<float4*>(pp) = *reinterpret_cast<const float4*>(p.ad_p + wi);
-            *reinterpret_cast<float4*>(pp + 4) = *reinterpret_cast<const float4*>(p.ad_p + wi + 4);
-            *reinterpret_cast<float4*>(mm) = *reinterpret_cast<const float4*>(p.ad_m + wi);
-            *reinterpret_cast<float4*>(mm + 4) = *reinterpret_cast<const float4*>(p.ad_m + wi + 4);
-            *reinterpret_cast<float4*>(vv) = *reinterpret_cast<const float4*>(p.ad_v + wi);
-            *reinterpret_cast<float4*>(vv + 4) = *reinterpret_cast<const float4*>(p.ad_v + wi + 4);
+            const int bf = ps & 1;
+            float pp[8] = {adp[bf][0].x, adp[bf][0].y, adp[bf][0].z, adp[bf][0].w, adp[bf][1].x, adp[bf][1].y, adp[bf][1].z, adp[bf][1].w};
+            float mm[8] = {adm[bf][0].x, adm[bf][0].y, adm[bf][0].z, adm[bf][0].w, adm[bf][1].x, adm[bf][1].y, adm[bf][1].z, adm[bf][1].w};
+            float vv[8] = {adv[bf][0].x, adv[bf][0].y, adv[bf][0].z, adv[bf][0].w, adv[bf][1].x, adv[bf][1].y, adv[bf][1].z, adv[bf][1].w};
 #pragma unroll
             for (int r = 0; r < 8; ++r) adamw_elem(pp[r], mm[r], vv[r], v[r], p.ad_decay, p.ad_b1, p.ad_b2, p.ad_eps, p.ad_step, p.ad_rsqrt_bc2);
-            *reinterpret_cast<float4*>(p.ad_p + wi) = *reinterpret_cast<float4*>(pp);
-            *reinterpret_cast<float4*>(p.ad_p + wi + 4) = *reinterpret_cast<float4*>(pp + 4);
-            *reinterpret_cast<float4*>(p.ad_m + wi) = *reinterpret_cast<float4*>(mm);
-            *reinterpret_cast<float4*>(p.ad_m + wi + 4) = *reinterpret_cast<float4*>(mm + 4);
-            *reinterpret_cast<float4*>(p.ad_v + wi) = *reinterpret_cast<float4*>(vv);
-            *reinterpret_cast<float4*>(p.ad_v + wi + 4) = *reinterpret_cast<float4*>(vv + 4);
+            *reinterpret_cast<float4*>(p.ad_p + wi) = make_float4(pp[0], pp[1], pp[2], pp[3]);
+            *reinterpret_cast<float4*>(p.ad_p + wi + 4) = make_float4(pp[4], pp[5], pp[6], pp[7]);
+            *reinterpret_cast<float4*>(p.ad_m + wi) = make_float4(mm[0], mm[1], mm[2], mm[3]);
+            *reinterpret_cast<float4*>(p.ad_m + wi + 4) = make_float4(mm[4], mm[5], mm[6], mm[7]);
+            *reinterpret_cast<float4*>(p.ad_v + wi) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+            *reinterpret_cast<float4*>(p.ad_v + wi + 4) = make_float4(vv[4], vv[5], vv[6], vv[7]);
             if (p.ad_shadow) {
                 bf16x8 o;
 #pragma unroll
