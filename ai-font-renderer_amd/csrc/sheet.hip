@@ -351,35 +351,32 @@ _Pragma("clang loop unroll_count(4) vectorize(disable) interleave(disable)")
                 mx = fmaxf(mx, dot8(q, kk));
             }
             mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
-            float sum = 0.f, num = 0.f;
-    #pragma clang loop unroll_count(2) vectorize(disable) interleave(disable)
-        for (int j = part; j < L; j += 2) {
+            // one pass for everything that depends on the softmax row: with p~ = exp(s - max) (unnormalised),
+            //   sum = S p~ ,  num = S p~ dA ,  T1 = S p~ dA k_j ,  T2 = S p~ k_j     (dA = (dO.v_j) * dropout mask)
+            // then  delta = num/sum  and  dq = scale * (T1 - delta * T2) / sum  ==  scale * S_j A_ij (dA_ij - delta) k_j
+            float sum = 0.f, num = 0.f, t1[D], t2[D];
+#pragma unroll
+            for (int d = 0; d < D; ++d) { t1[d] = 0.f; t2[d] = 0.f; }
+#pragma clang loop unroll_count(2) vectorize(disable) interleave(disable)
+            for (int j = part; j < L; j += 2) {
                 ld8(big + j * SQ + E + h * D, kk);
                 ld8(big + j * SQ + 2 * E + h * D, vv);
                 const float p = __expf(dot8(q, kk) - mx);
+                const float pa = p * (dot8(dO, vv) * attn_mask(dr, b, h, i, j, L));
                 sum += p;
-                num = fmaf(p, dot8(dO, vv) * attn_mask(dr, b, h, i, j, L), num);
+                num += pa;
+#pragma unroll
+                for (int d = 0; d < D; ++d) { t1[d] = fmaf(pa, kk[d], t1[d]); t2[d] = fmaf(p, kk[d], t2[d]); }
             }
             sum += __shfl_xor(sum, 1, 64);
             num += __shfl_xor(num, 1, 64);
             const float inv = 1.f / sum, delta = num * inv;
             if (part == 0) { smax[r] = mx; sinv[r] = inv; sdel[r] = delta; }
-            float dq[D];
-#pragma unroll
-            for (int d = 0; d < D; ++d) dq[d] = 0.f;
-    #pragma clang loop unroll_count(2) vectorize(disable) interleave(disable)
-        for (int j = part; j < L; j += 2) {
-                ld8(big + j * SQ + E + h * D, kk);
-                ld8(big + j * SQ + 2 * E + h * D, vv);
-                const float p = __expf(dot8(q, kk) - mx) * inv;
-                const float dS = p * (dot8(dO, vv) * attn_mask(dr, b, h, i, j, L) - delta);
-#pragma unroll
-                for (int d = 0; d < D; ++d) dq[d] = fmaf(dS, kk[d], dq[d]);
-            }
 #pragma unroll
             for (int d = 0; d < D; ++d) {
-                const float t2 = dq[d] + __shfl_xor(dq[d], 1, 64);
-                if (part == 0) o[i * SE + h * D + d] = t2 * scale;
+                const float a1 = t1[d] + __shfl_xor(t1[d], 1, 64);
+                const float a2 = t2[d] + __shfl_xor(t2[d], 1, 64);
+                if (part == 0) o[i * SE + h * D + d] = (a1 - delta * a2) * inv * scale;
             }
         }
         __syncthreads();
