@@ -7,7 +7,8 @@
 // saving activations (a sample's whole state is <100 KB of LDS), then walks it in reverse.
 //
 // One 1024-thread workgroup owns one string at a time and loops over strings (persistent grid, <= 256 blocks):
-// weights are loaded into LDS once.  Every reduction has a single owner thread and a fixed order -- no atomics:
+// weights are loaded into LDS once.  The small matmuls (in-proj, out-proj, fc1 and their data/weight gradients) run on
+// the matrix cores straight from LDS (exact-f32 v_mfma_f32_16x16x4_f32); the 100x100 attention stays on the VALU.  Every reduction has a single owner thread and a fixed order -- no atomics:
 //   * attention backward is split by ROW (softmax statistics, delta, dq) and then by COLUMN (dk, dv), each
 //     recomputing the scores it needs, so dv/dk need no scatter;
 //   * the 10 small parameter gradients accumulate across the block's strings in registers (dEmb in LDS, row v
@@ -25,6 +26,7 @@ constexpr int SE = 33, SQ = 100, SD = 36;       // LDS row strides: SE odd (conf
 #endif
 constexpr int NT = AFR_SHEET_NT;                // threads per workgroup: many waves hide the LDS/FMA latencies of the serial phases
 constexpr int NG = NT / 32;                     // 32-lane column groups (accumulator ownership)
+static_assert(NT == 1024, "the weight-gradient tile ownership below assumes 16 waves per workgroup");
 constexpr int W_FLOATS = QKV * SE + QKV + E * SE + E + E + E + F * SE + F;   // weights block
 
 struct Wts { float *Win, *bin, *Wo, *bo, *lg, *lb, *W1, *b1; };
@@ -56,6 +58,47 @@ __device__ __forceinline__ float dot8(const float (&a)[8], const float (&b)[8]) 
 }
 __device__ __forceinline__ int al4(int n) { return (n + 3) & ~3; }
 
+// Small LDS-resident matmul on the matrix cores: out(m,n) = sum_k A(m,k) * B(n,k), m<M, n<N, K a multiple of 4, with
+// A(m,k) = A[m*sa_m + k*sa_k] and B(n,k) = B[n*sb_n + k*sb_k] (any orientation: LDS is indexed freely).  16x16 output
+// tiles are dealt round-robin to the block's waves; each is a chain of exact-f32 v_mfma_f32_16x16x4_f32 (bitwise a
+// k-ordered fma chain).  Rows/columns past the edge are clamped on load (an MFMA output row depends only on its own
+// A row) and dropped by the epilogue bounds.  epi(m, n, value) is called once per valid output element.
+template <class Epi>
+__device__ __forceinline__ void lds_mma(const float* A, int sa_m, int sa_k, const float* B, int sb_n, int sb_k, int M, int N,
+                                        int K, int tid, Epi epi) {
+    const int wave = tid >> 6, lane = tid & 63;
+    const int tn = (N + 15) >> 4, tiles = ((M + 15) >> 4) * tn;
+    const int kq = lane >> 4, l15 = lane & 15;
+    for (int t = wave; t < tiles; t += NT / 64) {
+        const int m0 = (t / tn) << 4, n0 = (t % tn) << 4;
+        const float* ap = A + min(m0 + l15, M - 1) * sa_m + kq * sa_k;
+        const float* bp = B + min(n0 + l15, N - 1) * sb_n + kq * sb_k;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int k = 0; k < K; k += 4) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[k * sa_k], bp[k * sb_k], acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = m0 + 4 * kq + r, n = n0 + l15;
+            if (m < M && n < N) epi(m, n, acc[r]);
+        }
+    }
+}
+
+// One persistent 16x16 accumulator tile: acc += sum_{k<K} A(m0+i, k) * B(n0+j, k), any K (tail guarded).  Used for the
+// small weight gradients, whose accumulators stay in MFMA registers across all strings a block processes.
+__device__ __forceinline__ void lds_mma_tile(f32x4& acc, const float* A, int sa_m, int sa_k, const float* B, int sb_n, int sb_k,
+                                             int m0, int n0, int K, int lane) {
+    const int kq = lane >> 4, l15 = lane & 15;
+    const float* ap = A + (m0 + l15) * sa_m + kq * sa_k;
+    const float* bp = B + (n0 + l15) * sb_n + kq * sb_k;
+    const int K4 = K & ~3;
+    for (int k = 0; k < K4; k += 4) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[k * sa_k], bp[k * sb_k], acc, 0, 0, 0);
+    if (K4 < K) {
+        const bool ok = K4 + kq < K;
+        const float a = ok ? ap[K4 * sa_k] : 0.f, bq = ok ? bp[K4 * sb_k] : 0.f;
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bq, acc, 0, 0, 0);
+    }
+}
+
 // ---- shared forward pieces (used by both kernels so that backward's recomputation is bit-identical) ----------
 __device__ __forceinline__ void ph_tokens(int* tok, const int64_t* x, int ldx, int b, int L, int vocab, uint32_t* err, int tid) {
     if (tid < L) {
@@ -75,13 +118,7 @@ __device__ __forceinline__ void ph_embed(float* e, const int* tok, const SheetPa
 }
 // qkv = e . W_in^T + b_in                                                       (packed in-proj of nn.MultiheadAttention)
 __device__ __forceinline__ void ph_inproj(float* qkv, const float* e, const Wts& w, int L, int tid) {
-    for (int i = tid; i < L * QKV; i += NT) {
-        const int l = i / QKV, j = i - l * QKV;
-        float a = w.bin[j];
-#pragma unroll 8
-        for (int c = 0; c < E; ++c) a = fmaf(e[l * SE + c], w.Win[j * SE + c], a);
-        qkv[l * SQ + j] = a;
-    }
+    lds_mma(e, SE, 1, w.Win, SE, 1, L, QKV, E, tid, [&](int m, int n, float v) { qkv[m * SQ + n] = v + w.bin[n]; });
 }
 __device__ __forceinline__ float attn_mask(const SheetDrop& dr, int b, int h, int i, int j, int L) {
     if (!dr.training) return 1.f;
@@ -129,13 +166,7 @@ __device__ __forceinline__ void ph_attention(float* o, const float* qkv, const S
 }
 // r = e + o . W_o^T + b_o                                                       (model.py:176-180)
 __device__ __forceinline__ void ph_outproj_res(float* r, const float* e, const float* o, const Wts& w, int L, int tid) {
-    for (int i = tid; i < L * E; i += NT) {
-        const int l = i >> 5, c = i & 31;
-        float a = w.bo[c];
-#pragma unroll 8
-        for (int k = 0; k < E; ++k) a = fmaf(o[l * SE + k], w.Wo[c * SE + k], a);
-        r[l * SE + c] = e[l * SE + c] + a;
-    }
+    lds_mma(o, SE, 1, w.Wo, SE, 1, L, E, E, tid, [&](int m, int n, float v) { r[m * SE + n] = e[m * SE + n] + v + w.bo[n]; });
 }
 // LayerNorm over the 32 channels, biased variance: xh <- (r-mu)*rstd in place, n <- xh*gamma+beta, rstd kept
 __device__ __forceinline__ void ph_layernorm(float* xh, float* n, float* rstd, const Wts& w, int L, float eps, int tid) {
@@ -163,13 +194,6 @@ __device__ __forceinline__ float fc_mask(const SheetDrop& dr, int b, int L, int 
     if (!dr.training) return 1.f;
     return afr_keep((uint64_t)b * L * F + i, dr.key_f, dr.thr_f) ? dr.sc_f : 0.f;
 }
-__device__ __forceinline__ float fc1_pre(const float* n, const Wts& w, int l, int j) {
-    float a = w.b1[j];
-#pragma unroll 8
-    for (int c = 0; c < E; ++c) a = fmaf(n[l * SE + c], w.W1[j * SE + c], a);
-    return a;
-}
-
 // ------------------------------------------------------------------------------------------ forward kernel
 template <typename T>
 __global__ __launch_bounds__(NT) void sheet_fwd_kernel(SheetDims dm, SheetParams P, SheetDrop dr, const int64_t* __restrict__ x,
@@ -200,11 +224,10 @@ __global__ __launch_bounds__(NT) void sheet_fwd_kernel(SheetDims dm, SheetParams
         ph_layernorm(r, n, rstd, w, L, eps, tid);
         __syncthreads();
         T* zr = z + (size_t)b * Kz;
-        for (int i = tid; i < L * F; i += NT) {                    // fc1 + ReLU + dropout, model.py:183-184
-            const int l = i >> 6, j = i & 63;
-            const float f = fmaxf(fc1_pre(n, w, l, j), 0.f);
-            zr[i] = (T)(f * fc_mask(dr, b, L, i));
-        }
+        float* fbuf = qkv;                                          // qkv is dead: [L][64] ReLU outputs, then a coalesced copy-out
+        lds_mma(n, SE, 1, w.W1, SE, 1, L, F, E, tid, [&](int m, int j, float v) { fbuf[m * F + j] = fmaxf(v + w.b1[j], 0.f); });
+        __syncthreads();
+        for (int i = tid; i < L * F; i += NT) zr[i] = (T)(fbuf[i] * fc_mask(dr, b, L, i));      // fc1 + ReLU + dropout, model.py:183-184
         for (size_t i = (size_t)L * F + tid; i < Kz; i += NT) zr[i] = (T)0.f;   // zero-pad branch, model.py:190-193
         __syncthreads();
     }
@@ -239,15 +262,13 @@ __global__ __launch_bounds__(NT) void sheet_bwd_kernel(SheetDims dm, SheetParams
     for (int i = tid; i < dm.vocab * E; i += NT) demb[i] = 0.f;
 
     const int c32 = tid & 31, g8 = tid >> 5;          // g8: column group 0..NG-1
-    constexpr int KW1 = F / NG, KWO = E / NG, KWIN = QKV / NG, KPOS = (120 + NG - 1) / NG;
-    float aW1[KW1], aWo[KWO], aWin[KWIN], aPos[KPOS];
+    constexpr int KPOS = (120 + NG - 1) / NG;
+    float aPos[KPOS];
+    // weight-gradient tiles (16x16, MFMA accumulators, persistent across strings): 8 of dW1 [64x32], 4 of dWo [32x32],
+    // 12 of dWin [96x32].  Wave w owns tile w (accA); waves 0..7 also own dWin tile w+4 (accB).
+    f32x4 accA = {0.f, 0.f, 0.f, 0.f}, accB = {0.f, 0.f, 0.f, 0.f};
+    const int wave = tid >> 6, lane = tid & 63;
     float a_b1 = 0.f, a_bo = 0.f, a_g = 0.f, a_b = 0.f, a_bin = 0.f;
-#pragma unroll
-    for (int k = 0; k < KW1; ++k) aW1[k] = 0.f;
-#pragma unroll
-    for (int k = 0; k < KWO; ++k) aWo[k] = 0.f;
-#pragma unroll
-    for (int k = 0; k < KWIN; ++k) aWin[k] = 0.f;
 #pragma unroll
     for (int k = 0; k < KPOS; ++k) aPos[k] = 0.f;
     const float scale = 0.35355339059327373f;
@@ -269,29 +290,16 @@ __global__ __launch_bounds__(NT) void sheet_bwd_kernel(SheetDims dm, SheetParams
         __syncthreads();
         // ---- df = dz * dropout-mask * [pre>0]
         const T* dzr = dz + (size_t)b * Kz;
-        for (int i = tid; i < L * F; i += NT) {
-            const int l = i >> 6, j = i & 63;
-            const float pre = fc1_pre(nbuf, w, l, j);
-            df[i] = pre > 0.f ? (float)dzr[i] * fc_mask(dr, b, L, i) : 0.f;
-        }
+        for (int i = tid; i < L * F; i += NT) df[i] = (float)dzr[i] * fc_mask(dr, b, L, i);
         __syncthreads();
-        // ---- dW1 += df^T n ; db1 += sum df ; dn = df . W1
-#pragma clang loop unroll_count(4) vectorize(disable) interleave(disable)
-        for (int l = 0; l < L; ++l) {
-            const float nv = nbuf[l * SE + c32];
-#pragma unroll
-            for (int k = 0; k < KW1; ++k) aW1[k] = fmaf(df[l * F + g8 + NG * k], nv, aW1[k]);
-        }
+        lds_mma(nbuf, SE, 1, w.W1, SE, 1, L, F, E, tid, [&](int m, int j, float v) { if (!(v + w.b1[j] > 0.f)) df[m * F + j] = 0.f; });
+        __syncthreads();
+        // ---- dW1 += df^T n (persistent MFMA tiles) ; db1 += sum df ; dn = df . W1
+        if (wave < 8) lds_mma_tile(accA, df, 1, F, nbuf, 1, SE, 16 * (wave >> 1), 16 * (wave & 1), L, lane);
         if (tid < F) { float a = 0.f;
 _Pragma("clang loop unroll_count(4) vectorize(disable) interleave(disable)")
             for (int l = 0; l < L; ++l) a += df[l * F + tid]; a_b1 += a; }
-        for (int i = tid; i < L * E; i += NT) {
-            const int l = i >> 5, c = i & 31;
-            float a = 0.f;
-#pragma unroll 8
-            for (int j = 0; j < F; ++j) a = fmaf(df[l * F + j], w.W1[j * SE + c], a);
-            dn[l * SE + c] = a;
-        }
+        lds_mma(df, F, 1, w.W1, 1, SE, L, E, F, tid, [&](int m, int c, float v) { dn[m * SE + c] = v; });
         __syncthreads();
         // ---- LayerNorm backward: dgamma, dbeta (column owners), then dr in place (row owners)
         if (tid < E) { float a = 0.f;
@@ -314,23 +322,11 @@ _Pragma("clang loop unroll_count(4) vectorize(disable) interleave(disable)")
         }
         __syncthreads();
         // ---- out-proj backward: dWo += dr^T o ; dbo += sum dr ; dO = dr . Wo  (written over xhat, which is dead)
-#pragma clang loop unroll_count(4) vectorize(disable) interleave(disable)
-        for (int l = 0; l < L; ++l) {
-            const float ov = o[l * SE + c32];
-#pragma unroll
-            for (int k = 0; k < KWO; ++k) aWo[k] = fmaf(dn[l * SE + g8 + NG * k], ov, aWo[k]);
-        }
+        if (wave >= 8 && wave < 12) lds_mma_tile(accA, dn, 1, SE, o, 1, SE, 16 * ((wave - 8) >> 1), 16 * (wave & 1), L, lane);
         if (tid < E) { float a = 0.f;
 _Pragma("clang loop unroll_count(4) vectorize(disable) interleave(disable)")
             for (int l = 0; l < L; ++l) a += dn[l * SE + tid]; a_bo += a; }
-        __syncthreads();                                     // all reads of xhat (LN backward) are done
-        for (int i = tid; i < L * E; i += NT) {
-            const int l = i >> 5, c = i & 31;
-            float a = 0.f;
-#pragma unroll 8
-            for (int k = 0; k < E; ++k) a = fmaf(dn[l * SE + k], w.Wo[k * SE + c], a);
-            xh[l * SD + c] = a;
-        }
+        lds_mma(dn, SE, 1, w.Wo, 1, SE, L, E, E, tid, [&](int m, int c, float v) { xh[m * SD + c] = v; });
         __syncthreads();                                     // n, df dead; o dead after the dWo loop above
         ph_inproj(big, e, w, L, tid);                        // recompute qkv
         __syncthreads();
@@ -412,22 +408,19 @@ _Pragma("clang loop unroll_count(4) vectorize(disable) interleave(disable)")
         }
         __syncthreads();
         // ---- in-proj backward: dWin += dqkv^T e ; dbin += sum dqkv ; de = dr + dqkv . Win   (de in place over dr)
-#pragma clang loop unroll_count(4) vectorize(disable) interleave(disable)
-        for (int l = 0; l < L; ++l) {
-            const float ev = e[l * SE + c32];
-#pragma unroll
-            for (int k = 0; k < KWIN; ++k) aWin[k] = fmaf(dqkv_at(o, big, l, g8 + NG * k), ev, aWin[k]);
+        //      dqkv lives in two places: dq in `o` (columns 0..31), dk|dv in `big` (columns 32..95)
+        if (wave >= 12) {                                   // dWin tiles 0..3: rows j = 0..31 come from dq
+            const int id = wave - 12;
+            lds_mma_tile(accA, o, 1, SE, e, 1, SE, 16 * (id >> 1), 16 * (id & 1), L, lane);
+        } else if (wave < 8) {                              // dWin tiles 4..11: rows j = 32..95 come from dk|dv
+            const int id = wave + 4;
+            lds_mma_tile(accB, big, 1, SQ, e, 1, SE, 16 * (id >> 1), 16 * (id & 1), L, lane);
         }
         if (tid < QKV) { float a = 0.f;
 _Pragma("clang loop unroll_count(4) vectorize(disable) interleave(disable)")
             for (int l = 0; l < L; ++l) a += dqkv_at(o, big, l, tid); a_bin += a; }
-        for (int i = tid; i < L * E; i += NT) {
-            const int l = i >> 5, c = i & 31;
-            float a = dn[l * SE + c];
-#pragma unroll 8
-            for (int j = 0; j < QKV; ++j) a = fmaf(dqkv_at(o, big, l, j), w.Win[j * SE + c], a);
-            dn[l * SE + c] = a;
-        }
+        lds_mma(o, SE, 1, w.Win, 1, SE, L, E, E, tid, [&](int m, int c, float v) { dn[m * SE + c] += v; });
+        lds_mma(big + E, SQ, 1, w.Win + E * SE, 1, SE, L, E, 2 * E, tid, [&](int m, int c, float v) { dn[m * SE + c] += v; });
         __syncthreads();
         // ---- dP += de ; dEmb[tok] += de * embed-dropout-mask       (row v of dEmb owned by thread slot v%NG)
 #pragma unroll
@@ -448,15 +441,25 @@ _Pragma("clang loop unroll_count(4) vectorize(disable) interleave(disable)")
 #pragma unroll
     for (int k = 0; k < KPOS; ++k) { const int l = g8 + NG * k; if (l < L) S[so.pos + l * E + c32] = aPos[k]; }
     for (int i = tid; i < dm.vocab * E; i += NT) S[so.emb + i] = demb[i];
+    {   // MFMA D layout: row = 4*(lane>>4) + r, col = lane&15
+        const int kq = lane >> 4, l15 = lane & 15;
 #pragma unroll
-    for (int k = 0; k < KWIN; ++k) S[so.win + (g8 + NG * k) * E + c32] = aWin[k];
+        for (int r = 0; r < 4; ++r) {
+            if (wave < 8) {
+                S[so.w1 + (16 * (wave >> 1) + 4 * kq + r) * E + 16 * (wave & 1) + l15] = accA[r];
+                const int id = wave + 4;
+                S[so.win + (16 * (id >> 1) + 4 * kq + r) * E + 16 * (id & 1) + l15] = accB[r];
+            } else if (wave < 12) {
+                S[so.wo + (16 * ((wave - 8) >> 1) + 4 * kq + r) * E + 16 * (wave & 1) + l15] = accA[r];
+            } else {
+                const int id = wave - 12;
+                S[so.win + (16 * (id >> 1) + 4 * kq + r) * E + 16 * (id & 1) + l15] = accA[r];
+            }
+        }
+    }
     if (tid < QKV) S[so.bin + tid] = a_bin;
-#pragma unroll
-    for (int k = 0; k < KWO; ++k) S[so.wo + (g8 + NG * k) * E + c32] = aWo[k];
     if (tid < E) { S[so.bo + tid] = a_bo; S[so.g + tid] = a_g; }
     else if (tid < 2 * E) S[so.b + tid - E] = a_b;
-#pragma unroll
-    for (int k = 0; k < KW1; ++k) S[so.w1 + (g8 + NG * k) * E + c32] = aW1[k];
     if (tid < F) S[so.b1 + tid] = a_b1;
 }
 }  // namespace
