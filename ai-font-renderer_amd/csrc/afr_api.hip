@@ -522,7 +522,7 @@ static int backward_stage_impl(afr_plan* p, int stage, int64_t* g_off, int64_t* 
     // slab reductions: flushed per stage (so the stage's gradient range is final), or deferred to ONE grouped launch
     // at the end of a monolithic afr_backward (shared_rt)
     RTable local_rt;
-    local_rt.nseg = 0; local_rt.nblocks = 0;
+    local_rt.nseg = 0; local_rt.nblocks = 0; local_rt.adam = 0;
     RTable& rt = shared_rt ? *shared_rt : local_rt;
     auto flush = [&]() -> int { return shared_rt ? AFR_OK : run_reduce_group(p, s, rt); };
     if (c.kind == AFR_KIND_SHEET) {
@@ -612,7 +612,7 @@ extern "C" int afr_backward(afr_plan* p, void* stream) {
     if (!p->have_du) return fail(AFR_ESTATE, "afr_backward needs afr_forward + afr_loss_grad first");
     const int n = afr_backward_stages(p);
     RTable rt;
-    rt.nseg = 0; rt.nblocks = 0;
+    rt.nseg = 0; rt.nblocks = 0; rt.adam = 0;
     for (int st = 0; st < n; ++st) {
         int rc = backward_stage_impl(p, st, nullptr, nullptr, (hipStream_t)stream, &rt);
         if (rc) return rc;
@@ -635,6 +635,35 @@ extern "C" int afr_adamw_step(afr_plan* p, float lr, float b1, float b2, float e
     bf16_t* shadow = p->cfg.dtype == AFR_BF16 ? (bf16_t*)(p->ws + p->o_shadow) : nullptr;
     ProfScope ps(p, s, "adamw", 0.0, (double)p->total * (shadow ? 30.0 : 28.0));
     HIPCHK(afr_launch_adamw(p->P, p->G, p->M, p->V, shadow, p->total, lr, b1, b2, eps, wd, bc1, bc2, gscale, s));
+    return AFR_OK;
+}
+
+// Single-GPU optimiser step fused into the grouped slab reduction: every tensor whose gradient was produced as partial
+// slabs (split-K dW, bias partials, embedding partials, the sheet model's small tensors) is updated in the kernel that
+// sums its slabs -- the summed gradient is never stored; tensors whose gradient a GEMM wrote directly get the plain kernel.
+static int reduce_and_step(afr_plan* p, hipStream_t s, RTable& rt, float lr, float b1, float b2, float eps, float wd, int64_t t,
+                           int64_t skip_off = -1) {
+    const float bc1 = (float)(1.0 - std::pow((double)b1, (double)t));
+    const float bc2 = (float)(1.0 - std::pow((double)b2, (double)t));
+    bf16_t* shadow = p->cfg.dtype == AFR_BF16 ? (bf16_t*)(p->ws + p->o_shadow) : nullptr;
+    rt.adam = 1; rt.ad_decay = 1.f - lr * wd; rt.ad_b1 = b1; rt.ad_b2 = b2; rt.ad_eps = eps; rt.ad_step = lr / bc1;
+    rt.ad_rsqrt_bc2 = (float)(1.0 / std::sqrt((double)bc2));
+    rt.gbase = p->G; rt.P = p->P; rt.M = p->M; rt.V = p->V; rt.shadow = shadow;
+    int rc = run_reduce_group(p, s, rt);
+    if (rc) return rc;
+    for (const Tensor& tn : p->params) {
+        if (tn.off == skip_off) continue;
+        bool covered = false;
+        for (int i = 0; i < rt.nseg && !covered; ++i) {
+            const int64_t so = rt.seg[i].dst - p->G, sl = rt.seg[i].n4 * 4;
+            covered = tn.off >= so && tn.off + tn.numel <= so + sl;
+        }
+        if (covered) continue;
+        const int64_t n = (tn.numel + 63) / 64 * 64;
+        ProfScope ps(p, s, "adamw", 0.0, (double)n * 28.0);
+        HIPCHK(afr_launch_adamw(p->P + tn.off, p->G + tn.off, p->M + tn.off, p->V + tn.off, shadow ? shadow + tn.off : nullptr, n, lr, b1,
+                                b2, eps, wd, bc1, bc2, 1.f, s));
+    }
     return AFR_OK;
 }
 
@@ -672,15 +701,11 @@ static int sheet_fused_step(afr_plan* p, hipStream_t s, float lr, float b1, floa
                                     p->last_ldx, B, dz, c.ln_eps, slabs, so, s));
     }
     RTable rt;
-    rt.nseg = 0; rt.nblocks = 0;
+    rt.nseg = 0; rt.nblocks = 0; rt.adam = 0;
     afr_rtable_add(rt, p->G, slabs, afr_sheet_blocks(B), (long long)so.total, (long long)so.total);
-    if ((rc = run_reduce_group(p, s, rt))) return rc;
-    {   // the ten small tensors, then fc_output.bias
-        ProfScope ps(p, s, "adamw", 0.0, (double)(p->total - (p->s_bout - p->s_wout)) * 28.0);
-        HIPCHK(afr_launch_adamw(p->P, p->G, p->M, p->V, shadow, p->s_wout, lr, b1, b2, eps, wd, bc1, bc2, 1.f, s));
-        HIPCHK(afr_launch_adamw(p->P + p->s_bout, p->G + p->s_bout, p->M + p->s_bout, p->V + p->s_bout,
-                                shadow ? shadow + p->s_bout : nullptr, p->total - p->s_bout, lr, b1, b2, eps, wd, bc1, bc2, 1.f, s));
-    }
+    // the ten small tensors are updated inside the slab reduction; fc_output.bias by the plain kernel; fc_output.weight
+    // was updated in the dW GEMM above (skipped here)
+    if ((rc = reduce_and_step(p, s, rt, lr, b1, b2, eps, wd, t, p->s_wout))) return rc;
     p->have_du = false;
     p->next_stage = 0;
     return AFR_OK;
@@ -708,6 +733,17 @@ extern "C" int afr_train_step(afr_plan* p, const int64_t* x, const int64_t* font
     if (do_step && fused_step_eligible(p, B) && !(p->cfg.reserved & 1)) {
         if (t < 1) return fail(AFR_EINVAL, "t starts at 1");
         return sheet_fused_step(p, (hipStream_t)stream, lr, b1, b2, eps, wd, t);
+    }
+    if (do_step && p->M && p->V && !(p->cfg.reserved & 1)) {
+        if (t < 1) return fail(AFR_EINVAL, "t starts at 1");
+        const int n = afr_backward_stages(p);
+        RTable rt;
+        rt.nseg = 0; rt.nblocks = 0; rt.adam = 0;
+        for (int st = 0; st < n; ++st)
+            if ((rc = backward_stage_impl(p, st, nullptr, nullptr, (hipStream_t)stream, &rt))) return rc;
+        p->next_stage = 0;
+        p->have_du = false;
+        return reduce_and_step(p, (hipStream_t)stream, rt, lr, b1, b2, eps, wd, t);
     }
     if ((rc = afr_backward(p, stream))) return rc;
     if (do_step && (rc = afr_adamw_step(p, lr, b1, b2, eps, wd, t, 1.f, stream))) return rc;

@@ -47,6 +47,7 @@ hipError_t afr_launch_reduce(float* dst, const float* slabs, int nslabs, long lo
 }
 
 // ------------------------------------------------------------------------------ grouped reduce
+// (Optionally fused with AdamW: single-GPU steps update p/m/v right here and never materialise those gradients.)
 // One launch sums every slab-produced gradient of a backward pass (split-K dW slabs, fused bias partials, embedding
 // partials) into the flat gradient buffer, each in fixed slab order.  Block -> segment by a scan of <= 24 entries.
 __global__ __launch_bounds__(256) void reduce_group_kernel(RTable t) {
@@ -61,7 +62,23 @@ __global__ __launch_bounds__(256) void reduce_group_kernel(RTable t) {
             const float4 v = *reinterpret_cast<const float4*>(src + s * sg.stride);
             a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
         }
-        reinterpret_cast<float4*>(sg.dst)[i] = a;
+        if (t.adam) {
+            const long long off = (sg.dst - t.gbase) + 4 * i;
+            float4 pp = *reinterpret_cast<float4*>(t.P + off), mm = *reinterpret_cast<float4*>(t.M + off), vv = *reinterpret_cast<float4*>(t.V + off);
+            adamw_elem(pp.x, mm.x, vv.x, a.x, t.ad_decay, t.ad_b1, t.ad_b2, t.ad_eps, t.ad_step, t.ad_rsqrt_bc2);
+            adamw_elem(pp.y, mm.y, vv.y, a.y, t.ad_decay, t.ad_b1, t.ad_b2, t.ad_eps, t.ad_step, t.ad_rsqrt_bc2);
+            adamw_elem(pp.z, mm.z, vv.z, a.z, t.ad_decay, t.ad_b1, t.ad_b2, t.ad_eps, t.ad_step, t.ad_rsqrt_bc2);
+            adamw_elem(pp.w, mm.w, vv.w, a.w, t.ad_decay, t.ad_b1, t.ad_b2, t.ad_eps, t.ad_step, t.ad_rsqrt_bc2);
+            *reinterpret_cast<float4*>(t.P + off) = pp;
+            *reinterpret_cast<float4*>(t.M + off) = mm;
+            *reinterpret_cast<float4*>(t.V + off) = vv;
+            if (t.shadow) {
+                bf16x4 o = {(bf16_t)pp.x, (bf16_t)pp.y, (bf16_t)pp.z, (bf16_t)pp.w};
+                *reinterpret_cast<bf16x4*>(t.shadow + off) = o;
+            }
+        } else {
+            reinterpret_cast<float4*>(sg.dst)[i] = a;
+        }
     }
 }
 void afr_rtable_add(RTable& t, float* dst, const float* src, int nslabs, long long stride, long long n) {
@@ -286,7 +303,7 @@ hipError_t afr_launch_glyph_embed(int act_dtype, const float* emb, const float* 
 // embedding_dense_backward (model.py:309): dEmb[x[b]] += d[b].  Deterministic, atomic-free: a block takes 256 glyph
 // rows; thread (slot = tid>>5, c = tid&31) is the ONLY writer of LDS rows v with v%8 == slot, column c, and walks the
 // block's rows in order.  Block partials go to slabs[block][(vocab+n_fonts)*E]; afr_launch_reduce sums them in order.
-constexpr int EMB_BWD_ROWS = 64;
+constexpr int EMB_BWD_ROWS = 32;
 template <typename T>
 __global__ __launch_bounds__(256) void glyph_embed_bwd_kernel(const T* __restrict__ d, const int64_t* __restrict__ x,
                                                               const int64_t* __restrict__ font, int B, int E, int vocab,
