@@ -137,10 +137,15 @@ def main():
 
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    force_dp = os.environ.get("AFR_BENCH_FORCE_DP") == "1"      # rehearse the multi-rank code path with a world of one
+    if world > 1 or force_dp:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # nccl == RCCL on ROCm
+        os.environ.setdefault("MASTER_PORT", "29511")
+        if world > 1:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # nccl == RCCL on ROCm
+        else:
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
 
     from ai_font_renderer_amd.engine import Engine
     from ai_font_renderer_amd.parallel import DataParallelStepper
@@ -149,7 +154,7 @@ def main():
     x, font, tgt = make_inputs(name, cfg, B, rank)
     x, tgt = x.cuda(), tgt.cuda()
     font = font.cuda() if font is not None else None
-    stepper = DataParallelStepper(eng, dist, world)
+    stepper = DataParallelStepper(eng, dist, 2 if (force_dp and world == 1) else world)
     mean_elems = world * B * cfg.pixels
 
     def run(n):
