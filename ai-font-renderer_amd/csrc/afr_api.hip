@@ -49,7 +49,7 @@ struct afr_plan {
     char* ws = nullptr;
     size_t ws_bytes = 0, ws_need = 0;
     // workspace offsets (bytes)
-    size_t o_shadow = 0, o_err = 0, o_loss = 0, o_u = 0, o_z = 0, o_dz = 0, o_slab_e = 0;
+    size_t o_shadow = 0, o_err = 0, o_loss = 0, o_u = 0, o_z = 0, o_dz = 0, o_slab_e = 0, o_save = 0;
     std::vector<size_t> o_act;     // glyph: activations h0..h_nh
     size_t o_d[2] = {0, 0};        // glyph: ping-pong d buffers
     // glyph layer table
@@ -157,6 +157,7 @@ extern "C" int afr_plan_create(const afr_config* c, afr_plan** out) {
         if (ly.sk > 1) { ly.o_slab_w = carve((size_t)ly.sk * Pix * Kz * sizeof(float)); ly.o_slab_b = carve((size_t)ly.sk * Pix * sizeof(float)); }
         p->layers.push_back(ly);
         p->o_slab_e = carve((size_t)afr_sheet_blocks((int)B) * (size_t)p->s_wout * sizeof(float));
+        p->o_save = carve(B * (size_t)L * 40 * sizeof(float));
     } else if (c->kind == AFR_KIND_GLYPH) {
         if (c->n_hidden < 0 || c->n_hidden > AFR_MAX_HIDDEN) { delete p; return fail(AFR_EINVAL, "n_hidden out of range"); }
         if (E % 8) { delete p; return fail(AFR_EUNSUPPORTED, "embed_dim must be a multiple of 8"); }
@@ -409,6 +410,7 @@ static SheetDrop make_drop(const afr_plan* p, int training, uint64_t step) {
     d.sc_e = 1.f / (1.f - c.p_embed);
     d.sc_a = 1.f / (1.f - c.p_attn);
     d.sc_f = 1.f / (1.f - c.p_fc);
+    d.save = training ? (float*)(p->ws + p->o_save) : nullptr;     // only a training forward leaves o + softmax stats behind
     return d;
 }
 static SheetParams sheet_params(const afr_plan* p) {

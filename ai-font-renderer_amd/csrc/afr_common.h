@@ -167,7 +167,12 @@ struct SheetDims { int L, Lmax, E, H, F, vocab; };
 struct SheetParams {   // device pointers into the flat f32 parameter buffer
     const float *pos, *emb, *w_in, *b_in, *w_o, *b_o, *ln_g, *ln_b, *w1, *b1;
 };
-struct SheetDrop { uint32_t key_e, key_a, key_f, thr_e, thr_a, thr_f; float sc_e, sc_a, sc_f; int training; };
+struct SheetDrop {
+    uint32_t key_e, key_a, key_f, thr_e, thr_a, thr_f; float sc_e, sc_a, sc_f; int training;
+    // optional per-string save area written by a training forward and read by backward: [B][L*40] floats =
+    // attention output o [L][32], softmax row max [4][L], 1/row-sum [4][L]  (spares backward the attention recompute)
+    float* save;
+};
 // offsets (in floats) of the 10 small tensors inside one partial-gradient slab == their flat-buffer offsets
 struct SheetSlabOff { int pos, emb, win, bin, wo, bo, g, b, w1, b1, total; };
 int afr_sheet_blocks(int B);

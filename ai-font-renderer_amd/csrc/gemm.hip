@@ -293,7 +293,7 @@ __device__ __forceinline__ bf16x8 read_frag(const char* S, int xb, int ks, int l
 //         needs 25 % fewer DMA bytes per FLOP.
 template <int ALAY, int BLAY, int WM>
 __global__ __launch_bounds__(128 * WM, 2) void gemm_bf16(GemmParams p) {
-    constexpr int BM = 64 * WM, NW = 2 * WM, NTHR = 64 * NW, ASUB = WM / 2;
+    constexpr int BM = 64 * WM, NW = 2 * WM, ASUB = WM / 2;
     constexpr int STAGES = (WM == 4) ? 3 : 2;
     constexpr int STAGE_BYTES = (ASUB + 1) * SUB;
     constexpr int A_PER_WAVE = ASUB * 16 / NW, B_PER_WAVE = 16 / NW;

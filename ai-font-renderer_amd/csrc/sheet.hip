@@ -126,7 +126,8 @@ __device__ __forceinline__ float attn_mask(const SheetDrop& dr, int b, int h, in
     return afr_keep(idx, dr.key_a, dr.thr_a) ? dr.sc_a : 0.f;
 }
 // o = concat_h( dropout(softmax((q/sqrt(D)) k^T)) v )      two adjacent lanes per (head, query row), keys split even/odd
-__device__ __forceinline__ void ph_attention(float* o, const float* qkv, const SheetDrop& dr, int b, int L, int tid) {
+__device__ __forceinline__ void ph_attention(float* o, const float* qkv, const SheetDrop& dr, int b, int L, int tid,
+                                             float* smax_out = nullptr, float* sinv_out = nullptr) {
     const float scale = 0.35355339059327373f;    // sqrt(1/8), applied to q as torch does
     for (int rr = tid; rr < 2 * H * L; rr += NT) {
         const int r = rr >> 1, part = rr & 1;
@@ -157,6 +158,7 @@ __device__ __forceinline__ void ph_attention(float* o, const float* qkv, const S
         }
         sum += __shfl_xor(sum, 1, 64);
         const float inv = 1.f / sum;
+        if (smax_out && part == 0) { smax_out[r] = mx; sinv_out[r] = inv; }
 #pragma unroll
         for (int d = 0; d < D; ++d) {
             const float a = acc[d] + __shfl_xor(acc[d], 1, 64);
@@ -207,7 +209,9 @@ __global__ __launch_bounds__(NT) void sheet_fwd_kernel(SheetDims dm, SheetParams
     float* r = o + al4(L * SE);
     float* n = r + al4(L * SE);
     float* rstd = n + al4(L * SE);
-    int* tok = reinterpret_cast<int*>(rstd + al4(L));
+    float* smax = rstd + al4(L);       // [4L]
+    float* sinv = smax + H * L;        // [4L]
+    int* tok = reinterpret_cast<int*>(sinv + H * L);
     load_weights(w, P, tid);
     const size_t Kz = (size_t)dm.Lmax * F;
     for (int b = blockIdx.x; b < B; b += gridDim.x) {
@@ -217,8 +221,13 @@ __global__ __launch_bounds__(NT) void sheet_fwd_kernel(SheetDims dm, SheetParams
         __syncthreads();
         ph_inproj(qkv, e, w, L, tid);
         __syncthreads();
-        ph_attention(o, qkv, dr, b, L, tid);
+        ph_attention(o, qkv, dr, b, L, tid, dr.save ? smax : nullptr, sinv);
         __syncthreads();
+        if (dr.save) {                                              // keep o and the softmax statistics for backward
+            float* sv = dr.save + (size_t)b * L * 40;
+            for (int i = tid; i < L * E; i += NT) sv[i] = o[(i >> 5) * SE + (i & 31)];
+            for (int i = tid; i < H * L; i += NT) { sv[L * E + i] = smax[i]; sv[L * E + H * L + i] = sinv[i]; }
+        }
         ph_outproj_res(r, e, o, w, L, tid);
         __syncthreads();
         ph_layernorm(r, n, rstd, w, L, eps, tid);
@@ -280,9 +289,16 @@ __global__ __launch_bounds__(NT) void sheet_bwd_kernel(SheetDims dm, SheetParams
         __syncthreads();
         ph_embed(e, tok, P, dr, b, L, tid);
         __syncthreads();
-        ph_inproj(big, e, w, L, tid);
-        __syncthreads();
-        ph_attention(o, big, dr, b, L, tid);
+        const bool saved = dr.save != nullptr;
+        if (saved) {                                               // o and the softmax statistics come from the forward
+            const float* sv = dr.save + (size_t)b * L * 40;
+            for (int i = tid; i < L * E; i += NT) o[(i >> 5) * SE + (i & 31)] = sv[i];
+            for (int i = tid; i < H * L; i += NT) { smax[i] = sv[L * E + i]; sinv[i] = sv[L * E + H * L + i]; }
+        } else {
+            ph_inproj(big, e, w, L, tid);
+            __syncthreads();
+            ph_attention(o, big, dr, b, L, tid);
+        }
         __syncthreads();
         ph_outproj_res(xh, e, o, w, L, tid);
         __syncthreads();
@@ -340,13 +356,18 @@ _Pragma("clang loop unroll_count(4) vectorize(disable) interleave(disable)")
             ld8(xh + i * SD + h * D, dO);
 #pragma unroll
             for (int d = 0; d < D; ++d) q[d] *= scale;
-            float mx = -INFINITY;
-    #pragma clang loop unroll_count(2) vectorize(disable) interleave(disable)
-        for (int j = part; j < L; j += 2) {
-                ld8(big + j * SQ + E + h * D, kk);
-                mx = fmaxf(mx, dot8(q, kk));
+            float mx;
+            if (saved) {
+                mx = smax[r];
+            } else {
+                mx = -INFINITY;
+#pragma clang loop unroll_count(2) vectorize(disable) interleave(disable)
+                for (int j = part; j < L; j += 2) {
+                    ld8(big + j * SQ + E + h * D, kk);
+                    mx = fmaxf(mx, dot8(q, kk));
+                }
+                mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
             }
-            mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
             // one pass for everything that depends on the softmax row: with p~ = exp(s - max) (unnormalised),
             //   sum = S p~ ,  num = S p~ dA ,  T1 = S p~ dA k_j ,  T2 = S p~ k_j     (dA = (dO.v_j) * dropout mask)
             // then  delta = num/sum  and  dq = scale * (T1 - delta * T2) / sum  ==  scale * S_j A_ij (dA_ij - delta) k_j
@@ -467,7 +488,7 @@ _Pragma("clang loop unroll_count(4) vectorize(disable) interleave(disable)")
 int afr_sheet_blocks(int B) { return B < 256 ? B : 256; }
 static inline int al4h(int n) { return (n + 3) & ~3; }
 size_t afr_sheet_fwd_lds_bytes(const SheetDims& d) {
-    return (size_t)(W_FLOATS + 4 * al4h(d.L * SE) + d.L * SQ + 2 * al4h(d.L)) * sizeof(float);
+    return (size_t)(W_FLOATS + 4 * al4h(d.L * SE) + d.L * SQ + 2 * al4h(d.L) + 2 * H * d.L) * sizeof(float);
 }
 size_t afr_sheet_bwd_lds_bytes(const SheetDims& d) {
     return (size_t)(W_FLOATS + 3 * al4h(d.L * SE) + d.L * SD + d.L * SQ + al4h(d.L) + 3 * H * d.L + d.vocab * E + d.L) * sizeof(float);
