@@ -129,7 +129,7 @@ const char* afr_gemm_kernel_name(int dtype, const GemmParams& p);
 hipError_t afr_launch_reduce(float* dst, const float* slabs, int nslabs, long long slab_stride, long long n,
                              float scale, int accumulate, hipStream_t s);
 // grouped reduction: every gradient tensor that was produced as partial slabs, in ONE launch
-struct RSeg { float* dst; const float* src; long long stride; long long n4; int nslabs; int blk0; int nblk; int pad; };
+struct RSeg { float* dst; const float* src; long long stride; long long n4; int nslabs; int blk0; int nblk; int deep; };
 struct RTable {
     int nseg; int nblocks;
     // optional fused optimizer: the summed gradient is not stored; AdamW is applied to p/m/v at the same flat offset
