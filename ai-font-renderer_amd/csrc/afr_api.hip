@@ -52,6 +52,7 @@ struct afr_plan {
     size_t o_shadow = 0, o_err = 0, o_loss = 0, o_u = 0, o_z = 0, o_dz = 0, o_slab_e = 0, o_save = 0;
     std::vector<size_t> o_act;     // glyph: activations h0..h_nh
     size_t o_d[2] = {0, 0};        // glyph: ping-pong d buffers
+    size_t o_table = 0;            // glyph: [Emb; Font] . W1^T, the first Linear folded through the tables
     // glyph layer table
     struct Layer { int N, K; int64_t w_off, b_off; int sk = 1; size_t o_slab_w = 0, o_slab_b = 0; };
     std::vector<Layer> layers;
@@ -202,6 +203,7 @@ extern "C" int afr_plan_create(const afr_config* c, afr_plan** out) {
             if ((size_t)l.N > maxn) maxn = (size_t)l.N;
         }
         p->o_slab_e = carve((size_t)afr_embed_bwd_blocks((int)B) * (size_t)(c->vocab + c->n_fonts) * E * sizeof(float));
+        if (c->n_hidden > 0) p->o_table = carve((size_t)(c->vocab + c->n_fonts) * c->hidden[0] * sizeof(float));
     } else {
         delete p;
         return fail(AFR_EINVAL, "unknown model kind %d", c->kind);
@@ -451,13 +453,22 @@ static int forward_impl(afr_plan* p, const int64_t* x, const int64_t* font, int 
     } else {
         if (c.n_fonts > 0 && !font) return fail(AFR_EINVAL, "font ids are required when n_fonts > 0");
         void* h = p->ws + p->o_act[0];
-        {
-            ProfScope ps(p, s, "glyph_embed", 0.0, 0.0);
-            HIPCHK(afr_launch_glyph_embed(c.dtype, p->P + p->emb_off, c.n_fonts > 0 ? p->P + p->font_off : nullptr, x, font, B,
-                                          c.embed_dim, c.vocab, c.n_fonts, h, err, s));
-        }
         const int nl = (int)p->layers.size();
-        for (int i = 0; i < nl; ++i) {
+        const float* femb = c.n_fonts > 0 ? p->P + p->font_off : nullptr;
+        int first = 0;
+        if (nl >= 2) {
+            // hidden layer 1 as a table gather (see glyph_table_kernel); also leaves h0 for the backward dW GEMM
+            const auto& l = p->layers[0];
+            ProfScope ps(p, s, "glyph_l1_fwd", 0.0, (double)B * l.N * p->act_bytes);
+            HIPCHK(afr_launch_glyph_l1_fwd(c.dtype, p->P + p->emb_off, femb, p->P + l.w_off, p->P + l.b_off, x, font, B, c.embed_dim,
+                                           l.N, c.vocab, c.n_fonts, (float*)(p->ws + p->o_table), h, p->ws + p->o_act[1], err, s));
+            h = p->ws + p->o_act[1];
+            first = 1;
+        } else {
+            ProfScope ps(p, s, "glyph_embed", 0.0, 0.0);
+            HIPCHK(afr_launch_glyph_embed(c.dtype, p->P + p->emb_off, femb, x, font, B, c.embed_dim, c.vocab, c.n_fonts, h, err, s));
+        }
+        for (int i = first; i < nl; ++i) {
             const auto& l = p->layers[i];
             const bool last = (i == nl - 1);
             void* outp = last ? u : (void*)(p->ws + p->o_act[i + 1]);

@@ -350,6 +350,98 @@ hipError_t afr_launch_glyph_embed(int act_dtype, const float* emb, const float* 
     return hipGetLastError();
 }
 
+// First Linear folded through the embedding tables.  The glyph model feeds h0 = Emb[x] + Font[f] straight into
+// fc1 (no dropout, no nonlinearity in between), and a batch of thousands of glyphs draws from only vocab + n_fonts
+// distinct rows, so   fc1(h0)[b] = T[x_b] + T[vocab + f_b] + b1   with   T = [Emb; Font] . W1^T   ((vocab+n_fonts) x N1).
+// The table costs (vocab+n_fonts)*N1*E MACs per step instead of B*N1*E, stays in L2, and the layer becomes a gather.
+// table[r][n] = sum_k tab(r)[k] * W1[n][k];  grid (rows, ceil(N1/256))
+__global__ __launch_bounds__(256) void glyph_table_kernel(const float* __restrict__ emb, const float* __restrict__ femb,
+                                                          const float* __restrict__ W1, int vocab, int E, int N1,
+                                                          float* __restrict__ table) {
+    extern __shared__ float trow[];                       // this block's table-input row, E floats
+    const int r = blockIdx.x;
+    const float* src = r < vocab ? emb + (size_t)r * E : femb + (size_t)(r - vocab) * E;
+    for (int k = threadIdx.x; k < E; k += 256) trow[k] = src[k];
+    __syncthreads();
+    const int n = blockIdx.y * 256 + threadIdx.x;
+    if (n >= N1) return;
+    const float* w = W1 + (size_t)n * E;
+    float a = 0.f;
+    for (int k = 0; k < E; k += 4) {                      // E % 8 == 0 (checked at plan creation)
+        const float4 wv = *reinterpret_cast<const float4*>(w + k);
+        a = fmaf(trow[k], wv.x, a); a = fmaf(trow[k + 1], wv.y, a); a = fmaf(trow[k + 2], wv.z, a); a = fmaf(trow[k + 3], wv.w, a);
+    }
+    table[(size_t)r * N1 + n] = a;
+}
+// h1[b][n] = relu(T[x_b][n] + T[vocab+f_b][n] + b1[n]) and h0[b][:] = Emb[x_b] + Font[f_b] (the dW GEMM's operand).
+// One lane owns 8 consecutive n of one glyph.  Index checks as in glyph_embed_kernel.
+template <typename T>
+__global__ __launch_bounds__(256) void glyph_l1_fwd_kernel(const float* __restrict__ table, const float* __restrict__ b1,
+                                                           const float* __restrict__ emb, const float* __restrict__ femb,
+                                                           const int64_t* __restrict__ x, const int64_t* __restrict__ font,
+                                                           int B, int E, int N1, int vocab, int n_fonts,
+                                                           T* __restrict__ h0, T* __restrict__ h1, uint32_t* err_flag) {
+    const int per_row = N1 >> 3;
+    const long long total = (long long)B * per_row;
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int b = (int)(i / per_row), c = (int)(i % per_row);
+        long long xi = x[b];
+        if (xi < 0 || xi >= vocab) { if (c == 0) atomicOr(err_flag, 1u); xi = min(max(xi, 0ll), (long long)vocab - 1); }
+        long long fi = 0;
+        if (n_fonts > 0) {
+            fi = font ? font[b] : 0;
+            if (fi < 0 || fi >= n_fonts) { if (c == 0) atomicOr(err_flag, 1u); fi = min(max(fi, 0ll), (long long)n_fonts - 1); }
+        }
+        const int n = 8 * c;
+        const float* tc = table + (size_t)xi * N1 + n;
+        float v[8];
+        {
+            const float4 a0 = *reinterpret_cast<const float4*>(tc), a1 = *reinterpret_cast<const float4*>(tc + 4);
+            const float4 g0 = *reinterpret_cast<const float4*>(b1 + n), g1 = *reinterpret_cast<const float4*>(b1 + n + 4);
+            v[0] = a0.x + g0.x; v[1] = a0.y + g0.y; v[2] = a0.z + g0.z; v[3] = a0.w + g0.w;
+            v[4] = a1.x + g1.x; v[5] = a1.y + g1.y; v[6] = a1.z + g1.z; v[7] = a1.w + g1.w;
+        }
+        if (n_fonts > 0) {
+            const float* tf = table + (size_t)(vocab + fi) * N1 + n;
+            const float4 a0 = *reinterpret_cast<const float4*>(tf), a1 = *reinterpret_cast<const float4*>(tf + 4);
+            v[0] += a0.x; v[1] += a0.y; v[2] += a0.z; v[3] += a0.w; v[4] += a1.x; v[5] += a1.y; v[6] += a1.z; v[7] += a1.w;
+        }
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] = fmaxf(v[r], 0.f);
+        T* o = h1 + (size_t)b * N1 + n;
+        if constexpr (sizeof(T) == 2) {
+            bf16x8 w;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) w[r] = (bf16_t)v[r];
+            *reinterpret_cast<bf16x8*>(o) = w;
+        } else {
+            *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+            *reinterpret_cast<float4*>(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        }
+        for (int k = c; k < E; k += per_row) {                            // h0: the first E lanes of the row write one value each
+            float hv = emb[xi * E + k];
+            if (n_fonts > 0) hv += femb[fi * E + k];
+            h0[(size_t)b * E + k] = (T)hv;
+        }
+    }
+}
+hipError_t afr_launch_glyph_l1_fwd(int act_dtype, const float* emb, const float* font_emb, const float* W1, const float* b1,
+                                   const int64_t* x, const int64_t* font, int B, int E, int N1, int vocab, int n_fonts,
+                                   float* table, void* h0, void* h1, uint32_t* err_flag, hipStream_t s) {
+    if (B <= 0) return hipSuccess;
+    if ((N1 & 7) || (E & 3)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(glyph_table_kernel, dim3(vocab + n_fonts, (N1 + 255) / 256), dim3(256), E * sizeof(float), s, emb, font_emb,
+                       W1, vocab, E, N1, table);
+    dim3 g(grid_for((long long)B * (N1 / 8), 256, 4096)), b(256);
+    if (act_dtype == AFR_BF16)
+        hipLaunchKernelGGL(glyph_l1_fwd_kernel<bf16_t>, g, b, 0, s, table, b1, emb, font_emb, x, font, B, E, N1, vocab, n_fonts,
+                           (bf16_t*)h0, (bf16_t*)h1, err_flag);
+    else
+        hipLaunchKernelGGL(glyph_l1_fwd_kernel<float>, g, b, 0, s, table, b1, emb, font_emb, x, font, B, E, N1, vocab, n_fonts,
+                           (float*)h0, (float*)h1, err_flag);
+    return hipGetLastError();
+}
+
 // embedding_dense_backward (model.py:309): dEmb[x[b]] += d[b].  Deterministic, atomic-free: a block takes 256 glyph
 // rows; thread (slot = tid>>5, c = tid&31) is the ONLY writer of LDS rows v with v%8 == slot, column c, and walks the
 // block's rows in order.  Block partials go to slabs[block][(vocab+n_fonts)*E]; afr_launch_reduce sums them in order.

@@ -17,6 +17,7 @@
 // f32: register-staged (loads issued before the MFMAs, written to the other buffer after them).
 // k-strided operands keep their [k][x] orientation in LDS; the bf16 path reads them with ds_read_b64_tr_b16
 // (hardware transpose), the f32 path by plain indexing (one f32 per lane per MFMA).
+#include <cstdlib>
 #include "afr_common.h"
 #include "../../include/afr.h"
 
@@ -291,6 +292,14 @@ __device__ __forceinline__ bf16x8 read_frag(const char* S, int xb, int ks, int l
 //   WM=4: 256x128, 512 threads, 3-stage LDS ring (144 KiB), tile t+2 in flight behind a COUNTED vmcnt and a raw
 //         s_barrier: the main loop was latency-bound on global->LDS with one tile in flight, and the bigger tile
 //         needs 25 % fewer DMA bytes per FLOP.
+// p/m/v accessors of the fused AdamW epilogue.  Loads are ordinary (non-temporal loads measured 4 % slower); stores are
+// streaming: the values are not read again before the next step (measured -1 % on the R0 dW kernel).
+#define ADLD(ptr) (*reinterpret_cast<const float4*>(ptr))
+__device__ __forceinline__ void nt_st4(float* q, float4 v) {
+    const f32x4 w = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(w, reinterpret_cast<f32x4*>(q));
+}
+#define ADST(ptr, val) nt_st4(ptr, val)
 template <int ALAY, int BLAY, int WM>
 __global__ __launch_bounds__(128 * WM, 2) void gemm_bf16(GemmParams p) {
     constexpr int BM = 64 * WM, NW = 2 * WM, ASUB = WM / 2;
@@ -507,22 +516,30 @@ __global__ __launch_bounds__(128 * WM, 2) void gemm_bf16(GemmParams p) {
             }
         }
     }
-    // fused AdamW operands are double-buffered one pass ahead (6 x 16 B per pass)
-    float4 adp[2][2], adm[2][2], adv[2][2];
+    // fused AdamW operands run AD-1 passes ahead of their use (6 x 16 B per lane and pass).  The 4-wave kernel has the
+    // registers for three passes in flight (208 VGPRs at 2 waves/SIMD; measured 806 -> 777 us on R0), the 8-wave one not.
+#ifndef AFR_AD
+#define AFR_AD 4
+#endif
+    constexpr int AD = (WM == 2) ? AFR_AD : 2;
+    float4 adp[AD][2], adm[AD][2], adv[AD][2];
     auto load_adam = [&](int ps, int buf) {
         const int m = m0 + wm * 64 + ps * 8 + (lane >> 3);
         if (m < p.M && ncol) {
             const size_t wi = (size_t)m * p.ldc + n;
-            adp[buf][0] = *reinterpret_cast<const float4*>(p.ad_p + wi); adp[buf][1] = *reinterpret_cast<const float4*>(p.ad_p + wi + 4);
-            adm[buf][0] = *reinterpret_cast<const float4*>(p.ad_m + wi); adm[buf][1] = *reinterpret_cast<const float4*>(p.ad_m + wi + 4);
-            adv[buf][0] = *reinterpret_cast<const float4*>(p.ad_v + wi); adv[buf][1] = *reinterpret_cast<const float4*>(p.ad_v + wi + 4);
+            adp[buf][0] = ADLD(p.ad_p + wi); adp[buf][1] = ADLD(p.ad_p + wi + 4);
+            adm[buf][0] = ADLD(p.ad_m + wi); adm[buf][1] = ADLD(p.ad_m + wi + 4);
+            adv[buf][0] = ADLD(p.ad_v + wi); adv[buf][1] = ADLD(p.ad_v + wi + 4);
         }
     };
-    if (p.ad_p) load_adam(0, 0);
+    if (p.ad_p) {
+#pragma unroll
+        for (int q = 0; q < AD - 1; ++q) load_adam(q, q);
+    }
 #pragma unroll
     for (int ps = 0; ps < 8; ++ps) {
         const int rl = ps * 8 + (lane >> 3);
-        if (p.ad_p && ps + 1 < 8) load_adam(ps + 1, (ps + 1) & 1);
+        if (p.ad_p && ps + AD - 1 < 8) load_adam(ps + AD - 1, (ps + AD - 1) % AD);
         const f32x4 lo = *reinterpret_cast<const f32x4*>(Wt + rl * 64 + (((2 * c8) ^ (rl & 15)) << 2));
         const f32x4 hi = *reinterpret_cast<const f32x4*>(Wt + rl * 64 + (((2 * c8 + 1) ^ (rl & 15)) << 2));
         float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
@@ -554,18 +571,18 @@ __global__ __launch_bounds__(128 * WM, 2) void gemm_bf16(GemmParams p) {
         }
         if (p.ad_p) {                                  // fused AdamW: v[] is the gradient of weight elements (m, n..n+7)
             const size_t wi = (size_t)m * p.ldc + n;
-            const int bf = ps & 1;
+            const int bf = ps % AD;
             float pp[8] = {adp[bf][0].x, adp[bf][0].y, adp[bf][0].z, adp[bf][0].w, adp[bf][1].x, adp[bf][1].y, adp[bf][1].z, adp[bf][1].w};
             float mm[8] = {adm[bf][0].x, adm[bf][0].y, adm[bf][0].z, adm[bf][0].w, adm[bf][1].x, adm[bf][1].y, adm[bf][1].z, adm[bf][1].w};
             float vv[8] = {adv[bf][0].x, adv[bf][0].y, adv[bf][0].z, adv[bf][0].w, adv[bf][1].x, adv[bf][1].y, adv[bf][1].z, adv[bf][1].w};
 #pragma unroll
             for (int r = 0; r < 8; ++r) adamw_elem(pp[r], mm[r], vv[r], v[r], p.ad_decay, p.ad_b1, p.ad_b2, p.ad_eps, p.ad_step, p.ad_rsqrt_bc2);
-            *reinterpret_cast<float4*>(p.ad_p + wi) = make_float4(pp[0], pp[1], pp[2], pp[3]);
-            *reinterpret_cast<float4*>(p.ad_p + wi + 4) = make_float4(pp[4], pp[5], pp[6], pp[7]);
-            *reinterpret_cast<float4*>(p.ad_m + wi) = make_float4(mm[0], mm[1], mm[2], mm[3]);
-            *reinterpret_cast<float4*>(p.ad_m + wi + 4) = make_float4(mm[4], mm[5], mm[6], mm[7]);
-            *reinterpret_cast<float4*>(p.ad_v + wi) = make_float4(vv[0], vv[1], vv[2], vv[3]);
-            *reinterpret_cast<float4*>(p.ad_v + wi + 4) = make_float4(vv[4], vv[5], vv[6], vv[7]);
+            ADST(p.ad_p + wi, make_float4(pp[0], pp[1], pp[2], pp[3]));
+            ADST(p.ad_p + wi + 4, make_float4(pp[4], pp[5], pp[6], pp[7]));
+            ADST(p.ad_m + wi, make_float4(mm[0], mm[1], mm[2], mm[3]));
+            ADST(p.ad_m + wi + 4, make_float4(mm[4], mm[5], mm[6], mm[7]));
+            ADST(p.ad_v + wi, make_float4(vv[0], vv[1], vv[2], vv[3]));
+            ADST(p.ad_v + wi + 4, make_float4(vv[4], vv[5], vv[6], vv[7]));
             if (p.ad_shadow) {
                 bf16x8 o;
 #pragma unroll
@@ -599,6 +616,10 @@ __global__ __launch_bounds__(128 * WM, 2) void gemm_bf16(GemmParams p) {
 // ---------------------------------------------------------------------------------------- launch
 // bf16: the 256x128 / 8-wave kernel when its grid fills most of the 256 CUs, else 128x128 / 4 waves
 static bool bf16_use_wide(const GemmParams& p) {
+    // a fused-AdamW epilogue moves 26 B per output element and is the longer half of such a kernel; two 128x128 blocks
+    // per CU (64 KiB of LDS each) let one block's epilogue run under the other's K loop, one 256x128 block cannot
+    static const int wide_adam = getenv("AFR_ADAM_WIDE") ? atoi(getenv("AFR_ADAM_WIDE")) : 0;
+    if (p.ad_p && !wide_adam) return false;
     const long long t = (long long)((p.M + 255) / 256) * ((p.N + 127) / 128) * p.splitk;
     return t >= 192 && p.K / p.splitk >= 256;      // the 3-stage ring needs a few K-tiles to pay
 }

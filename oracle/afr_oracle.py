@@ -170,12 +170,16 @@ def glyph_forward(P, x, font, cfg, rnd=None, relu_masks=None):
     h = P["embedding.weight"][x]
     if cfg.n_fonts > 0:
         h = h + P["font_embedding.weight"][font]
+    h_exact = h
     h = rnd(h)
     acts = [h]
     nh = len(cfg.hidden)
     pres, rmasks = [], []
     for i in range(nh):
-        pre = h @ rnd(P[f"fc{i + 1}.weight"]).t() + P[f"fc{i + 1}.bias"]
+        if i == 0:      # the bf16 engine evaluates fc1 from the f32 tables and weights (no rounding before its ReLU)
+            pre = h_exact @ P["fc1.weight"].t() + P["fc1.bias"]
+        else:
+            pre = h @ rnd(P[f"fc{i + 1}.weight"]).t() + P[f"fc{i + 1}.bias"]
         pres.append(pre)
         rmasks.append((pre > 0) if relu_masks is None else relu_masks[i])
         h = rnd(pre * rmasks[i].to(pre.dtype))
