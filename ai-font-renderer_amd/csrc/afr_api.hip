@@ -53,6 +53,8 @@ struct afr_plan {
     std::vector<size_t> o_act;     // glyph: activations h0..h_nh
     size_t o_d[2] = {0, 0};        // glyph: ping-pong d buffers
     size_t o_table = 0;            // glyph: [Emb; Font] . W1^T, the first Linear folded through the tables
+    size_t o_dw1 = 0;              // glyph: compact dW1 [N1][E] extracted from the widened weight-gradient slabs
+    int k0 = 0;                    // glyph: columns of h0' = [h0 | one-hot] when the first layer is folded, else 0
     // glyph layer table
     struct Layer { int N, K; int64_t w_off, b_off; int sk = 1; size_t o_slab_w = 0, o_slab_b = 0; };
     std::vector<Layer> layers;
@@ -189,7 +191,9 @@ extern "C" int afr_plan_create(const afr_config* c, afr_plan** out) {
         p->o_err = carve(256);
         p->o_loss = carve(((size_t)((B + 127) / 128) * ((Pix + 127) / 128) + 1040) * sizeof(float));
         size_t maxw = (size_t)E, maxn = 0;
-        p->o_act.push_back(carve(B * E * ab));
+        p->k0 = c->n_hidden > 0 ? afr_glyph_k0(E, c->vocab, c->n_fonts) : 0;
+        if (p->k0 > 512 || E > 128) p->k0 = 0;     // beyond what the folded-layer kernels stage per block: plain embedding + GEMM path
+        p->o_act.push_back(carve(B * (size_t)(p->k0 ? p->k0 : E) * ab));
         for (int i = 0; i < c->n_hidden; ++i) {
             p->o_act.push_back(carve(B * (size_t)c->hidden[i] * ab));
             if ((size_t)c->hidden[i] > maxw) maxw = (size_t)c->hidden[i];
@@ -197,13 +201,23 @@ extern "C" int afr_plan_create(const afr_config* c, afr_plan** out) {
         p->o_u = carve(B * Pix * ab);
         p->o_d[0] = carve(B * maxw * ab);
         p->o_d[1] = carve(B * maxw * ab);
+        bool first = true;
         for (auto& l : p->layers) {
-            l.sk = choose_splitk(l.N, l.K, (int)B);
-            if (l.sk > 1) { l.o_slab_w = carve((size_t)l.sk * l.N * l.K * sizeof(float)); l.o_slab_b = carve((size_t)l.sk * l.N * sizeof(float)); }
+            // the folded first layer's weight-gradient GEMM is K0 wide and always lands in slabs (even a single one)
+            const int kw = (first && p->k0) ? p->k0 : l.K;
+            l.sk = choose_splitk(l.N, kw, (int)B);
+            if (l.sk > 1 || (first && p->k0)) { l.o_slab_w = carve((size_t)l.sk * l.N * kw * sizeof(float)); l.o_slab_b = carve((size_t)l.sk * l.N * sizeof(float)); }
             if ((size_t)l.N > maxn) maxn = (size_t)l.N;
+            first = false;
         }
-        p->o_slab_e = carve((size_t)afr_embed_bwd_blocks((int)B) * (size_t)(c->vocab + c->n_fonts) * E * sizeof(float));
-        if (c->n_hidden > 0) p->o_table = carve((size_t)(c->vocab + c->n_fonts) * c->hidden[0] * sizeof(float));
+        size_t eb = (size_t)afr_embed_bwd_blocks((int)B);
+        if (p->k0) {
+            const size_t lb = (size_t)afr_glyph_l1_bwd_blocks(c->hidden[0]);
+            if (lb > eb) eb = lb;
+            p->o_table = carve((size_t)(c->vocab + c->n_fonts) * c->hidden[0] * sizeof(float));
+            p->o_dw1 = carve((size_t)c->hidden[0] * E * sizeof(float));
+        }
+        p->o_slab_e = carve(eb * (size_t)(c->vocab + c->n_fonts) * E * sizeof(float));
     } else {
         delete p;
         return fail(AFR_EINVAL, "unknown model kind %d", c->kind);
@@ -456,7 +470,7 @@ static int forward_impl(afr_plan* p, const int64_t* x, const int64_t* font, int 
         const int nl = (int)p->layers.size();
         const float* femb = c.n_fonts > 0 ? p->P + p->font_off : nullptr;
         int first = 0;
-        if (nl >= 2) {
+        if (p->k0) {
             // hidden layer 1 as a table gather (see glyph_table_kernel); also leaves h0 for the backward dW GEMM
             const auto& l = p->layers[0];
             ProfScope ps(p, s, "glyph_l1_fwd", 0.0, (double)B * l.N * p->act_bytes);
@@ -573,6 +587,37 @@ static int backward_stage_impl(afr_plan* p, int stage, int64_t* g_off, int64_t* 
     const void* a = p->ws + p->o_act[i];
     // d(loss)/d(output of layer i): du for the last layer, else the ping-pong buffer the previous stage wrote
     const void* dy = stage == 0 ? du : (const void*)(p->ws + p->o_d[(stage - 1) & 1]);
+    if (i == 0 && p->k0) {
+        // folded first layer (glyph_l1_bwd_kernel): ONE weight-gradient GEMM against h0' = [h0 | one-hot] yields dW1, db1
+        // and the per-table-row segment sums; a small kernel turns those into dEmb / dFont.  No input-gradient GEMM,
+        // no scatter-add.
+        const int K0 = p->k0, E = c.embed_dim;
+        int sk = choose_splitk(l.N, K0, B);
+        if (sk > l.sk) sk = l.sk;
+        float* sw = (float*)(p->ws + l.o_slab_w);
+        float* sb = (float*)(p->ws + l.o_slab_b);
+        const long long stride = (long long)l.N * K0;
+        const int gfl = AFR_GEMM_A_KSTRIDED | AFR_GEMM_B_KSTRIDED;
+        if (sk == 1) rc = run_gemm(p, s, gfl, dy, a, sw, nullptr, nullptr, l.N, K0, B, l.N, K0, K0, 0, 1, 0, p->G + l.b_off, 0);
+        else rc = run_gemm(p, s, gfl, dy, a, sw, nullptr, nullptr, l.N, K0, B, l.N, K0, K0, 0, sk, stride, sb, l.N);
+        if (rc) return rc;
+        if (sk > 1) afr_rtable_add(rt, p->G + l.b_off, sb, sk, l.N, l.N);
+        float* dw1 = (float*)(p->ws + p->o_dw1);
+        float* part = (float*)(p->ws + p->o_slab_e);
+        {
+            ProfScope ps(p, s, "glyph_l1_bwd", 0.0, (double)sk * l.N * K0 * 4.0);
+            HIPCHK(afr_launch_glyph_l1_bwd(sw, sk, stride, p->P + l.w_off, l.N, E, c.vocab, c.n_fonts, dw1, part, s));
+        }
+        const int nb = afr_glyph_l1_bwd_blocks(l.N);
+        const long long pstride = (long long)(c.vocab + c.n_fonts) * E;
+        afr_rtable_add(rt, p->G + l.w_off, dw1, 1, 0, (long long)l.N * E);
+        afr_rtable_add(rt, p->G + p->emb_off, part, nb, pstride, (long long)c.vocab * E);
+        if (c.n_fonts > 0) afr_rtable_add(rt, p->G + p->font_off, part + (size_t)c.vocab * E, nb, pstride, (long long)c.n_fonts * E);
+        if ((rc = flush())) return rc;
+        if (g_off) *g_off = 0;
+        if (g_len) *g_len = l.b_off + (l.N + 63) / 64 * 64;
+        return AFR_OK;
+    }
     if ((rc = run_dw(p, s, l, dy, a, B, rt))) return rc;
     void* dx = p->ws + p->o_d[stage & 1];
     const int fl = AFR_GEMM_B_KSTRIDED | ob | (i > 0 ? AFR_GEMM_RELU_MASK : 0);
@@ -784,7 +829,7 @@ extern "C" int afr_debug_copy(afr_plan* p, int which, void* dst, size_t cap, siz
     else if (which >= AFR_BUF_ACT && c.kind == AFR_KIND_GLYPH && which - AFR_BUF_ACT < (int)p->o_act.size()) {
         const int i = which - AFR_BUF_ACT;
         off = p->o_act[i];
-        bytes = B * (size_t)(i == 0 ? c.embed_dim : c.hidden[i - 1]) * ab;
+        bytes = B * (size_t)(i == 0 ? (p->k0 ? p->k0 : c.embed_dim) : c.hidden[i - 1]) * ab;
     } else return fail(AFR_EINVAL, "no such buffer %d for this model kind", which);
     if (bytes > cap) return fail(AFR_EINVAL, "destination too small: %zu < %zu", cap, bytes);
     HIPCHK(hipMemcpyAsync(dst, p->ws + off, bytes, hipMemcpyDefault, (hipStream_t)stream));

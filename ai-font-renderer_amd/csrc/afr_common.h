@@ -161,6 +161,10 @@ int afr_embed_bwd_blocks(int B);
 hipError_t afr_launch_glyph_l1_fwd(int act_dtype, const float* emb, const float* font_emb, const float* W1, const float* b1,
                                    const int64_t* x, const int64_t* font, int B, int E, int N1, int vocab, int n_fonts,
                                    float* table, void* h0, void* h1, uint32_t* err_flag, hipStream_t s);
+int afr_glyph_k0(int E, int vocab, int n_fonts);
+int afr_glyph_l1_bwd_blocks(int N1);
+hipError_t afr_launch_glyph_l1_bwd(const float* slabs, int nslabs, long long slab_stride, const float* W1, int N1, int E,
+                                   int vocab, int n_fonts, float* dw1, float* dtab_part, hipStream_t s);
 hipError_t afr_launch_glyph_embed_bwd(int act_dtype, const void* d, const int64_t* x, const int64_t* font, int B,
                                       int E, int vocab, int n_fonts, float* slabs /*[blocks][(vocab+n_fonts)*E]*/,
                                       hipStream_t s);

@@ -2,9 +2,11 @@
 // the glyph embedding gather and its deterministic scatter-add (bias gradients are fused into the dW GEMM).
 // All are 16-byte-per-lane streaming kernels with grid-stride loops; reductions are shuffle -> LDS ->
 // per-block partial -> fixed-order finish, so every result is bitwise reproducible run to run.
+#include <algorithm>
 #include "afr_common.h"
 #include "../../include/afr.h"
 
+int afr_glyph_k0(int E, int vocab, int n_fonts);
 static inline int grid_for(long long work_items, int block, int max_blocks = 2048) {
     long long g = (work_items + block - 1) / block;
     if (g < 1) g = 1;
@@ -354,34 +356,63 @@ hipError_t afr_launch_glyph_embed(int act_dtype, const float* emb, const float* 
 // fc1 (no dropout, no nonlinearity in between), and a batch of thousands of glyphs draws from only vocab + n_fonts
 // distinct rows, so   fc1(h0)[b] = T[x_b] + T[vocab + f_b] + b1   with   T = [Emb; Font] . W1^T   ((vocab+n_fonts) x N1).
 // The table costs (vocab+n_fonts)*N1*E MACs per step instead of B*N1*E, stays in L2, and the layer becomes a gather.
-// table[r][n] = sum_k tab(r)[k] * W1[n][k];  grid (rows, ceil(N1/256))
+// table[r][n] = sum_k tab(r)[k] * W1[n][k].  A block stages 256 fc1 rows (coalesced, padded to E+1 in LDS) and 8 table
+// rows, one thread per n; grid (ceil(rows/8), ceil(N1/256)).
+constexpr int GT_ROWS = 8;
 __global__ __launch_bounds__(256) void glyph_table_kernel(const float* __restrict__ emb, const float* __restrict__ femb,
-                                                          const float* __restrict__ W1, int vocab, int E, int N1,
+                                                          const float* __restrict__ W1, int vocab, int rows, int E, int N1,
                                                           float* __restrict__ table) {
-    extern __shared__ float trow[];                       // this block's table-input row, E floats
-    const int r = blockIdx.x;
-    const float* src = r < vocab ? emb + (size_t)r * E : femb + (size_t)(r - vocab) * E;
-    for (int k = threadIdx.x; k < E; k += 256) trow[k] = src[k];
-    __syncthreads();
-    const int n = blockIdx.y * 256 + threadIdx.x;
-    if (n >= N1) return;
-    const float* w = W1 + (size_t)n * E;
-    float a = 0.f;
-    for (int k = 0; k < E; k += 4) {                      // E % 8 == 0 (checked at plan creation)
-        const float4 wv = *reinterpret_cast<const float4*>(w + k);
-        a = fmaf(trow[k], wv.x, a); a = fmaf(trow[k + 1], wv.y, a); a = fmaf(trow[k + 2], wv.z, a); a = fmaf(trow[k + 3], wv.w, a);
+    extern __shared__ float sm[];                         // W [256][E+1] | tab [GT_ROWS][E]
+    float* Ws = sm;
+    float* tab = sm + 256 * (E + 1);
+    const int r0 = blockIdx.x * GT_ROWS, n0 = blockIdx.y * 256;
+    const int nn = min(256, N1 - n0), nr = min(GT_ROWS, rows - r0);
+    const int E4 = E >> 2;
+    for (int i = threadIdx.x; i < nn * E4; i += 256) {
+        const float4 v = *reinterpret_cast<const float4*>(W1 + (size_t)n0 * E + 4 * i);
+        float* d = Ws + (i / E4) * (E + 1) + 4 * (i % E4);
+        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
     }
-    table[(size_t)r * N1 + n] = a;
+    for (int i = threadIdx.x; i < nr * E; i += 256) {
+        const int r = r0 + i / E, k = i % E;
+        tab[i] = r < vocab ? emb[(size_t)r * E + k] : femb[(size_t)(r - vocab) * E + k];
+    }
+    __syncthreads();
+    if ((int)threadIdx.x >= nn) return;
+    const float* w = Ws + threadIdx.x * (E + 1);
+    float a[GT_ROWS];
+#pragma unroll
+    for (int j = 0; j < GT_ROWS; ++j) a[j] = 0.f;
+    for (int k = 0; k < E; ++k) {
+        const float wv = w[k];
+#pragma unroll
+        for (int j = 0; j < GT_ROWS; ++j) a[j] = fmaf(tab[j * E + k], wv, a[j]);   // rows past nr read stale LDS; never stored
+    }
+    for (int j = 0; j < nr; ++j) table[(size_t)(r0 + j) * N1 + n0 + threadIdx.x] = a[j];
 }
-// h1[b][n] = relu(T[x_b][n] + T[vocab+f_b][n] + b1[n]) and h0[b][:] = Emb[x_b] + Font[f_b] (the dW GEMM's operand).
-// One lane owns 8 consecutive n of one glyph.  Index checks as in glyph_embed_kernel.
+// h1[b][n] = relu(T[x_b][n] + T[vocab+f_b][n] + b1[n]), one lane per 8 consecutive n of one glyph; index checks as in
+// glyph_embed_kernel.  Also leaves the backward's GEMM operand h0' [B][K0]: h0 = Emb[x_b] + Font[f_b] followed by the
+// one-hot code of the two table rows the glyph used (see glyph_l1_bwd_kernel).
+template <typename T>
+__device__ __forceinline__ void store8(T* q, const float (&v)[8]) {
+    if constexpr (sizeof(T) == 2) {
+        bf16x8 w;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) w[r] = (bf16_t)v[r];
+        __builtin_nontemporal_store(w, reinterpret_cast<bf16x8*>(q));
+    } else {
+        const f32x4 lo = {v[0], v[1], v[2], v[3]}, hi = {v[4], v[5], v[6], v[7]};
+        __builtin_nontemporal_store(lo, reinterpret_cast<f32x4*>(q));
+        __builtin_nontemporal_store(hi, reinterpret_cast<f32x4*>(q) + 1);
+    }
+}
 template <typename T>
 __global__ __launch_bounds__(256) void glyph_l1_fwd_kernel(const float* __restrict__ table, const float* __restrict__ b1,
                                                            const float* __restrict__ emb, const float* __restrict__ femb,
                                                            const int64_t* __restrict__ x, const int64_t* __restrict__ font,
-                                                           int B, int E, int N1, int vocab, int n_fonts,
+                                                           int B, int E, int N1, int vocab, int n_fonts, int K0,
                                                            T* __restrict__ h0, T* __restrict__ h1, uint32_t* err_flag) {
-    const int per_row = N1 >> 3;
+    const int c1 = N1 >> 3, c0 = K0 >> 3, per_row = c1 + c0;      // 8-column chunks of h1, then of h0'
     const long long total = (long long)B * per_row;
     for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
         const int b = (int)(i / per_row), c = (int)(i % per_row);
@@ -392,36 +423,40 @@ __global__ __launch_bounds__(256) void glyph_l1_fwd_kernel(const float* __restri
             fi = font ? font[b] : 0;
             if (fi < 0 || fi >= n_fonts) { if (c == 0) atomicOr(err_flag, 1u); fi = min(max(fi, 0ll), (long long)n_fonts - 1); }
         }
-        const int n = 8 * c;
-        const float* tc = table + (size_t)xi * N1 + n;
         float v[8];
-        {
+        if (c < c1) {
+            const int n = 8 * c;
+            const float* tc = table + (size_t)xi * N1 + n;
             const float4 a0 = *reinterpret_cast<const float4*>(tc), a1 = *reinterpret_cast<const float4*>(tc + 4);
             const float4 g0 = *reinterpret_cast<const float4*>(b1 + n), g1 = *reinterpret_cast<const float4*>(b1 + n + 4);
             v[0] = a0.x + g0.x; v[1] = a0.y + g0.y; v[2] = a0.z + g0.z; v[3] = a0.w + g0.w;
             v[4] = a1.x + g1.x; v[5] = a1.y + g1.y; v[6] = a1.z + g1.z; v[7] = a1.w + g1.w;
-        }
-        if (n_fonts > 0) {
-            const float* tf = table + (size_t)(vocab + fi) * N1 + n;
-            const float4 a0 = *reinterpret_cast<const float4*>(tf), a1 = *reinterpret_cast<const float4*>(tf + 4);
-            v[0] += a0.x; v[1] += a0.y; v[2] += a0.z; v[3] += a0.w; v[4] += a1.x; v[5] += a1.y; v[6] += a1.z; v[7] += a1.w;
-        }
+            if (n_fonts > 0) {
+                const float* tf = table + (size_t)(vocab + fi) * N1 + n;
+                const float4 f0 = *reinterpret_cast<const float4*>(tf), f1 = *reinterpret_cast<const float4*>(tf + 4);
+                v[0] += f0.x; v[1] += f0.y; v[2] += f0.z; v[3] += f0.w; v[4] += f1.x; v[5] += f1.y; v[6] += f1.z; v[7] += f1.w;
+            }
 #pragma unroll
-        for (int r = 0; r < 8; ++r) v[r] = fmaxf(v[r], 0.f);
-        T* o = h1 + (size_t)b * N1 + n;
-        if constexpr (sizeof(T) == 2) {
-            bf16x8 w;
-#pragma unroll
-            for (int r = 0; r < 8; ++r) w[r] = (bf16_t)v[r];
-            *reinterpret_cast<bf16x8*>(o) = w;
+            for (int r = 0; r < 8; ++r) v[r] = fmaxf(v[r], 0.f);
+            store8(h1 + (size_t)b * N1 + n, v);
         } else {
-            *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
-            *reinterpret_cast<float4*>(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
-        }
-        for (int k = c; k < E; k += per_row) {                            // h0: the first E lanes of the row write one value each
-            float hv = emb[xi * E + k];
-            if (n_fonts > 0) hv += femb[fi * E + k];
-            h0[(size_t)b * E + k] = (T)hv;
+            // h0' = [h0 | one-hot of x_b | one-hot of vocab + f_b | zero pad]
+            const int k0 = 8 * (c - c1);
+            if (k0 < E) {                                     // E % 8 == 0: a chunk is all h0 or all one-hot
+                const float* e = emb + (size_t)xi * E + k0;
+                const float4 a0 = *reinterpret_cast<const float4*>(e), a1 = *reinterpret_cast<const float4*>(e + 4);
+                v[0] = a0.x; v[1] = a0.y; v[2] = a0.z; v[3] = a0.w; v[4] = a1.x; v[5] = a1.y; v[6] = a1.z; v[7] = a1.w;
+                if (n_fonts > 0) {
+                    const float* f = femb + (size_t)fi * E + k0;
+                    const float4 f0 = *reinterpret_cast<const float4*>(f), f1 = *reinterpret_cast<const float4*>(f + 4);
+                    v[0] += f0.x; v[1] += f0.y; v[2] += f0.z; v[3] += f0.w; v[4] += f1.x; v[5] += f1.y; v[6] += f1.z; v[7] += f1.w;
+                }
+            } else {
+                const int r0 = k0 - E, hx = (int)xi, hf = n_fonts > 0 ? vocab + (int)fi : -1;
+#pragma unroll
+                for (int r = 0; r < 8; ++r) v[r] = (r0 + r == hx || r0 + r == hf) ? 1.f : 0.f;
+            }
+            store8(h0 + (size_t)b * K0 + k0, v);
         }
     }
 }
@@ -429,16 +464,86 @@ hipError_t afr_launch_glyph_l1_fwd(int act_dtype, const float* emb, const float*
                                    const int64_t* x, const int64_t* font, int B, int E, int N1, int vocab, int n_fonts,
                                    float* table, void* h0, void* h1, uint32_t* err_flag, hipStream_t s) {
     if (B <= 0) return hipSuccess;
-    if ((N1 & 7) || (E & 3)) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(glyph_table_kernel, dim3(vocab + n_fonts, (N1 + 255) / 256), dim3(256), E * sizeof(float), s, emb, font_emb,
-                       W1, vocab, E, N1, table);
-    dim3 g(grid_for((long long)B * (N1 / 8), 256, 4096)), b(256);
+    if ((N1 & 7) || (E & 7)) return hipErrorInvalidValue;
+    const int K0 = afr_glyph_k0(E, vocab, n_fonts);
+    const int rows = vocab + n_fonts;
+    hipLaunchKernelGGL(glyph_table_kernel, dim3((rows + GT_ROWS - 1) / GT_ROWS, (N1 + 255) / 256), dim3(256),
+                       (256 * (E + 1) + GT_ROWS * E) * sizeof(float), s, emb, font_emb, W1, vocab, rows, E, N1, table);
+    dim3 g(grid_for((long long)B * ((N1 + K0) / 8), 256, 8192)), b(256);
     if (act_dtype == AFR_BF16)
-        hipLaunchKernelGGL(glyph_l1_fwd_kernel<bf16_t>, g, b, 0, s, table, b1, emb, font_emb, x, font, B, E, N1, vocab, n_fonts,
+        hipLaunchKernelGGL(glyph_l1_fwd_kernel<bf16_t>, g, b, 0, s, table, b1, emb, font_emb, x, font, B, E, N1, vocab, n_fonts, K0,
                            (bf16_t*)h0, (bf16_t*)h1, err_flag);
     else
-        hipLaunchKernelGGL(glyph_l1_fwd_kernel<float>, g, b, 0, s, table, b1, emb, font_emb, x, font, B, E, N1, vocab, n_fonts,
+        hipLaunchKernelGGL(glyph_l1_fwd_kernel<float>, g, b, 0, s, table, b1, emb, font_emb, x, font, B, E, N1, vocab, n_fonts, K0,
                            (float*)h0, (float*)h1, err_flag);
+    return hipGetLastError();
+}
+
+// columns of h0': E + (vocab + n_fonts) rounded up to 8
+int afr_glyph_k0(int E, int vocab, int n_fonts) { return E + (vocab + n_fonts + 7) / 8 * 8; }
+
+// Backward of the folded first layer.  The weight-gradient GEMM ran against h0' = [h0 | one-hot], so its split-K slabs
+// hold, per fc1 row n, both dW1[n][0..E) and S[n][r] = sum over the glyphs that used table row r of d1[b][n] -- the
+// segment sums that nn.Embedding's backward (model.py:309) needs, obtained on MFMA instead of a scatter-add.  Then
+//     dTab[r][k] = sum_n S[n][r] W1[n][k]        (dEmb = rows < vocab, dFont = the rest)
+// replaces the B x E x N1 input-gradient GEMM and the per-glyph scatter.  A block owns GL1_ROWS fc1 rows: it sums their
+// slabs (fixed order), emits the compact dW1 rows and its partial dTab, which the grouped reduce sums in block order.
+constexpr int GL1_ROWS = 8, GL1_NT = 1024;
+__global__ __launch_bounds__(GL1_NT) void glyph_l1_bwd_kernel(const float* __restrict__ slabs, int nslabs, long long slab_stride,
+                                                              const float* __restrict__ W1, int N1, int E, int R, int K0,
+                                                              float* __restrict__ dw1, float* __restrict__ dtab_part) {
+    extern __shared__ float sm[];                 // S [GL1_ROWS][K0] | W [GL1_ROWS][E] | part [G-1][GL1_ROWS*K0]
+    float* S = sm;
+    float* W = sm + GL1_ROWS * K0;
+    float* part = W + GL1_ROWS * E;
+    const int n0 = blockIdx.x * GL1_ROWS;
+    const int nr = min(GL1_ROWS, N1 - n0);
+    const int cnt4 = nr * K0 / 4;                 // K0 % 8 == 0; <= GL1_ROWS*K0/4 float4 columns
+    // the block's threads form G groups of cnt4 lanes; group g sums slabs g, g+G, ... (all loads of a lane independent),
+    // then the groups are added in group order
+    const int full4 = GL1_ROWS * K0 / 4;
+    const int G = max(1, min(GL1_NT / full4, 8));
+    const int g = threadIdx.x / full4, i = threadIdx.x % full4;
+    if (g < G && i < cnt4) {
+        const float* src = slabs + (size_t)n0 * K0 + 4 * i;
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4
+        for (int z = g; z < nslabs; z += G) {
+            const float4 v = *reinterpret_cast<const float4*>(src + (long long)z * slab_stride);
+            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+        }
+        float* dst = g == 0 ? S : part + (size_t)(g - 1) * GL1_ROWS * K0;
+        *reinterpret_cast<float4*>(dst + 4 * i) = a;
+    }
+    for (int j = threadIdx.x; j < nr * E; j += GL1_NT) W[j] = W1[(size_t)n0 * E + j];
+    __syncthreads();
+    if ((int)threadIdx.x < cnt4) {
+        float4 a = *reinterpret_cast<float4*>(S + 4 * threadIdx.x);
+        for (int q = 1; q < G; ++q) {
+            const float4 v = *reinterpret_cast<const float4*>(part + (size_t)(q - 1) * GL1_ROWS * K0 + 4 * threadIdx.x);
+            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+        }
+        *reinterpret_cast<float4*>(S + 4 * threadIdx.x) = a;
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < nr * E; j += GL1_NT) dw1[(size_t)n0 * E + j] = S[(j / E) * K0 + (j % E)];
+    float* out = dtab_part + (size_t)blockIdx.x * R * E;
+    for (int j = threadIdx.x; j < R * E; j += GL1_NT) {
+        const int r = j / E, k = j % E;
+        float a = 0.f;
+        for (int q = 0; q < nr; ++q) a = fmaf(S[q * K0 + E + r], W[q * E + k], a);
+        out[j] = a;
+    }
+}
+int afr_glyph_l1_bwd_blocks(int N1) { return (N1 + GL1_ROWS - 1) / GL1_ROWS; }
+hipError_t afr_launch_glyph_l1_bwd(const float* slabs, int nslabs, long long slab_stride, const float* W1, int N1, int E,
+                                   int vocab, int n_fonts, float* dw1, float* dtab_part, hipStream_t s) {
+    const int K0 = afr_glyph_k0(E, vocab, n_fonts);
+    if (GL1_ROWS * K0 / 4 > GL1_NT) return hipErrorInvalidValue;      // K0 <= 512: vocab + n_fonts + E within one block
+    const int G = std::max(1, std::min(GL1_NT / (GL1_ROWS * K0 / 4), 8));
+    const size_t lds = ((size_t)GL1_ROWS * (K0 + E) + (size_t)(G - 1) * GL1_ROWS * K0) * sizeof(float);
+    hipLaunchKernelGGL(glyph_l1_bwd_kernel, dim3(afr_glyph_l1_bwd_blocks(N1)), dim3(GL1_NT), lds, s, slabs, nslabs, slab_stride, W1, N1,
+                       E, vocab + n_fonts, K0, dw1, dtab_part);
     return hipGetLastError();
 }
 

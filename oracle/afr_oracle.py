@@ -201,8 +201,10 @@ def glyph_backward(P, cache, du, cfg, rnd=None):
         d = rnd(d * cache["rmasks"][i].to(d.dtype))
         G[f"fc{i + 1}.weight"] = d.t() @ acts[i]
         G[f"fc{i + 1}.bias"] = d.sum(0)
-        d = d @ rnd(P[f"fc{i + 1}.weight"])
-    d = rnd(d)
+        # the bf16 engine folds fc1's input gradient into table-row sums in f32 (no rounded d0 exists there)
+        d = d @ (P["fc1.weight"] if i == 0 else rnd(P[f"fc{i + 1}.weight"]))
+    if nh == 0:
+        d = rnd(d)
     dEmb = torch.zeros_like(P["embedding.weight"])
     dEmb.index_add_(0, cache["x"], d)
     G["embedding.weight"] = dEmb
