@@ -3,8 +3,9 @@
 The reference is single-device (model.py:95-106); sharding is new.  Samples are independent, so
 the batch is cut into contiguous row slices, one per rank, with NO data-path collective; the only exchange per
 step is the sum all-reduce of the flat gradient buffer (all parameters of state_dict() live in one contiguous
-float32 buffer), issued as two RCCL calls: the last layer's range asynchronously as soon as backward has produced
-it (overlapping the rest of the backward pass), the remainder when backward is done.  Every shard divides its loss by the GLOBAL element count
+float32 buffer).  Large models issue it as two RCCL calls: the last layer's range asynchronously as soon as backward has
+produced it (overlapping the rest of the backward pass), the remainder when backward is done; small ones (< 64 MB of
+gradients) as one call after backward.  Every shard divides its loss by the GLOBAL element count
 (`mean_elems`), so the summed gradients equal the full-batch gradients exactly, also for uneven last batches
 (192 / 304 rows in the reference's loaders).  Parameters, AdamW moments and the step counter are replicated;
 each rank draws its own dropout stream (rank is part of the counter-hash key).
@@ -21,6 +22,12 @@ def shard_rows(n_rows, rank, world):
     return slice(start, start + base + (1 if rank < rem else 0))
 
 
+# Below this gradient size the step uses ONE all-reduce after a monolithic backward: the overlapped two-collective
+# schedule costs ~33 us of staging and cross-stream hand-offs per step (measured with a world of one on the 8.5 MB C3
+# model: 274 us against 240 us), more than the transfer time it could hide.  The sheet model (492 MB) overlaps.
+OVERLAP_MIN_BYTES = 64 << 20
+
+
 class DataParallelStepper:
     def __init__(self, engine, dist=None, world=1):
         self.engine, self.dist, self.world = engine, dist, int(world)
@@ -33,7 +40,7 @@ class DataParallelStepper:
             return
         opt = {k: v for k, v in hyper.items() if k in ("lr", "betas", "eps", "weight_decay")}
         stages = getattr(eng, "backward_stages", 0)
-        if stages:
+        if stages and eng.flat_grads.numel() * 4 >= OVERLAP_MIN_BYTES:
             # Backward runs last layer first.  Two collectives per step: the last layer's gradient range (half of the
             # bytes in the glyph nets, 99.98 % in the sheet model) is all-reduced ASYNCHRONOUSLY as soon as stage 0 has
             # produced it and overlaps the rest of the backward pass; everything else is one contiguous range

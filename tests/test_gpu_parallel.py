@@ -55,9 +55,13 @@ def test_staged_backward_equals_monolithic_and_covers_the_buffer(kind):
         assert torch.equal(eng.flat_grads[o:o + n], ref[o:o + n]), name
 
 
-def test_data_parallel_stepper_over_rccl_world1():
+@pytest.mark.parametrize("schedule", ["one-allreduce", "overlapped"])
+def test_data_parallel_stepper_over_rccl_world1(schedule, monkeypatch):
     import torch.distributed as dist
+    from ai_font_renderer_amd import parallel
     from ai_font_renderer_amd.parallel import DataParallelStepper
+    # small models take one all-reduce after backward; force the two-collective overlapped schedule for the other case
+    monkeypatch.setattr(parallel, "OVERLAP_MIN_BYTES", 0 if schedule == "overlapped" else 1 << 40)
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", str(29600 + os.getpid() % 300))
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))

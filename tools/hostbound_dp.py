@@ -34,5 +34,10 @@ def onear():
     dist.all_reduce(eng.flat_grads)
     eng.adamw_step()
 print('staged-one-blocking-allreduce host/wall us', timeit(onear))
+def mono():
+    eng.train_step(x, t, font=font, mean_elems=me, do_step=False)
+    dist.all_reduce(eng.flat_grads)
+    eng.adamw_step()
+print('monolithic-backward-one-allreduce host/wall us', timeit(mono))
 print('fused-single host/wall us', timeit(lambda: eng.train_step(x, t, font=font)))
 dist.destroy_process_group()
