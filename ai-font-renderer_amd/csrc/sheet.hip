@@ -28,6 +28,19 @@ constexpr int NT = AFR_SHEET_NT;                // threads per workgroup: many w
 constexpr int NG = NT / 32;                     // 32-lane column groups (accumulator ownership)
 static_assert(NT == 1024, "the weight-gradient tile ownership below assumes 16 waves per workgroup");
 constexpr int W_FLOATS = QKV * SE + QKV + E * SE + E + E + E + F * SE + F;   // weights block
+// LDS buffers sit at fixed offsets sized for the longest supported string (LMAX): a block owns its CU's LDS anyway, and
+// compile-time addresses keep ~15 pointers out of the register file (the backward kernel is register-bound at 128 VGPRs).
+constexpr int LMAX = 120;
+constexpr int al4c(int n) { return (n + 3) & ~3; }
+constexpr int O_E = W_FLOATS, O_BIG = O_E + al4c(LMAX * SE), O_O = O_BIG + LMAX * SQ, O_XH = O_O + al4c(LMAX * SE),
+              O_DN = O_XH + LMAX * SD, O_RSTD = O_DN + al4c(LMAX * SE), O_SMAX = O_RSTD + al4c(LMAX), O_SINV = O_SMAX + H * LMAX,
+              O_SDEL = O_SINV + H * LMAX, O_REDA = O_SDEL + H * LMAX, O_REDB = O_REDA + 256, O_TOK = O_REDB + 256,
+              O_NXT = O_TOK + LMAX, BWD_FLOATS = O_NXT + LMAX;
+// forward: e | qkv | o | r | n | rstd | smax | sinv | tok
+constexpr int F_E = W_FLOATS, F_QKV = F_E + al4c(LMAX * SE), F_O = F_QKV + LMAX * SQ, F_R = F_O + al4c(LMAX * SE),
+              F_N = F_R + al4c(LMAX * SE), F_RSTD = F_N + al4c(LMAX * SE), F_SMAX = F_RSTD + al4c(LMAX), F_SINV = F_SMAX + H * LMAX,
+              F_TOK = F_SINV + H * LMAX, FWD_FLOATS = F_TOK + LMAX;
+static_assert(BWD_FLOATS * 4 <= 160 * 1024 && FWD_FLOATS * 4 <= 160 * 1024, "one string's state must fit the CU's LDS");
 
 struct Wts { float *Win, *bin, *Wo, *bo, *lg, *lb, *W1, *b1; };
 
@@ -171,24 +184,28 @@ __device__ __forceinline__ void ph_outproj_res(float* r, const float* e, const f
     lds_mma(o, SE, 1, w.Wo, SE, 1, L, E, E, tid, [&](int m, int n, float v) { r[m * SE + n] = e[m * SE + n] + v + w.bo[n]; });
 }
 // LayerNorm over the 32 channels, biased variance: xh <- (r-mu)*rstd in place, n <- xh*gamma+beta, rstd kept
+__device__ __forceinline__ float sum8(float v) {           // sum over the 8 adjacent lanes that share a row
+    v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64);
+    return v;
+}
 __device__ __forceinline__ void ph_layernorm(float* xh, float* n, float* rstd, const Wts& w, int L, float eps, int tid) {
-    if (tid < L) {
-        float* row = xh + tid * SE;
-        float mu = 0.f;
-#pragma unroll 8
-        for (int c = 0; c < E; ++c) mu += row[c];
-        mu *= (1.f / E);
+    // 8 lanes per row, 4 channels each (L <= 120 rows fit the block's 1024 threads)
+    const int l = tid >> 3, c0 = (tid & 7) * 4;
+    if (l < L) {
+        float* row = xh + l * SE + c0;
+        float v[4] = {row[0], row[1], row[2], row[3]};
+        const float mu = sum8((v[0] + v[1]) + (v[2] + v[3])) * (1.f / E);
         float var = 0.f;
-#pragma unroll 8
-        for (int c = 0; c < E; ++c) { const float dlt = row[c] - mu; var = fmaf(dlt, dlt, var); }
-        var *= (1.f / E);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { v[j] -= mu; var = fmaf(v[j], v[j], var); }
+        var = sum8(var) * (1.f / E);
         const float rs = 1.f / sqrtf(var + eps);
-        rstd[tid] = rs;
-#pragma unroll 8
-        for (int c = 0; c < E; ++c) {
-            const float xv = (row[c] - mu) * rs;
-            row[c] = xv;
-            n[tid * SE + c] = fmaf(xv, w.lg[c], w.lb[c]);
+        if ((tid & 7) == 0) rstd[l] = rs;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float xv = v[j] * rs;
+            row[j] = xv;
+            n[l * SE + c0 + j] = fmaf(xv, w.lg[c0 + j], w.lb[c0 + j]);
         }
     }
 }
@@ -203,15 +220,15 @@ __global__ __launch_bounds__(NT) void sheet_fwd_kernel(SheetDims dm, SheetParams
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int tid = threadIdx.x, L = dm.L;
     const Wts w = carve_weights(sm);
-    float* e = sm + W_FLOATS;
-    float* qkv = e + al4(L * SE);
-    float* o = qkv + L * SQ;
-    float* r = o + al4(L * SE);
-    float* n = r + al4(L * SE);
-    float* rstd = n + al4(L * SE);
-    float* smax = rstd + al4(L);       // [4L]
-    float* sinv = smax + H * L;        // [4L]
-    int* tok = reinterpret_cast<int*>(sinv + H * L);
+    float* const e = sm + F_E;
+    float* const qkv = sm + F_QKV;
+    float* const o = sm + F_O;
+    float* const r = sm + F_R;
+    float* const n = sm + F_N;
+    float* const rstd = sm + F_RSTD;
+    float* const smax = sm + F_SMAX;   // [4L]
+    float* const sinv = sm + F_SINV;   // [4L]
+    int* const tok = reinterpret_cast<int*>(sm + F_TOK);
     load_weights(w, P, tid);
     const size_t Kz = (size_t)dm.Lmax * F;
     for (int b = blockIdx.x; b < B; b += gridDim.x) {
@@ -247,106 +264,159 @@ __device__ __forceinline__ float dqkv_at(const float* dq, const float* big, int 
     return j < E ? dq[l * SE + j] : big[l * SQ + j];
 }
 
+// Phase timing for kernel development: build with -DAFR_SHEET_TIMING and block 0 prints per-phase totals (10 ns ticks).
+#ifdef AFR_SHEET_TIMING
+#define TMARK(k) do { __syncthreads(); if (threadIdx.x == 0) { const long long t_ = wall_clock64(); tacc[k] += t_ - tlast; tlast = t_; } } while (0)
+#else
+#define TMARK(k) do { } while (0)
+#endif
+// partial column sums of an [L][ncols] LDS array: thread t < ncols*P owns column t%ncols and rows t/ncols, +P, ... ; the
+// P partials per column land in red[part*ncols + c] and are added by the column's owner after the next barrier
+template <class F>
+__device__ __forceinline__ void col_partials(float* red, int t, int ncols, int P, int L, F at) {
+    if (t < 0 || t >= ncols * P) return;
+    const int c = t % ncols, part = t / ncols;
+    float a = 0.f;
+_Pragma("clang loop unroll_count(4) vectorize(disable) interleave(disable)")
+    for (int l = part; l < L; l += P) a += at(l, c);
+    red[part * ncols + c] = a;
+}
+__device__ __forceinline__ float col_total(const float* red, int c, int ncols, int P) {
+    float a = 0.f;
+    for (int q = 0; q < P; ++q) a += red[q * ncols + c];
+    return a;
+}
+
 template <typename T>
 __global__ __launch_bounds__(NT) void sheet_bwd_kernel(SheetDims dm, SheetParams P, SheetDrop dr, const int64_t* __restrict__ x,
                                                         int ldx, int B, const T* __restrict__ dz, float eps,
                                                         float* __restrict__ slabs, SheetSlabOff so) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    const int tid = threadIdx.x, L = dm.L;
+    const int tid0 = threadIdx.x, L = dm.L;
     const Wts w = carve_weights(sm);
-    float* e = sm + W_FLOATS;          // [L][33]   whole sample
-    float* big = e + al4(L * SE);      // [L][100]  qkv  | later n [L][33] + df [L][64] | later qkv again -> dk,dv in place
-    float* o = big + L * SQ;           // [L][33]   o    | later dq
-    float* xh = o + al4(L * SE);       // [L][36]   r -> xhat (stride 33) | later dO, grad wrt attention output (stride 36)
-    float* dn = xh + L * SD;           // [L][33]   dn -> dr -> de
-    float* rstd = dn + al4(L * SE);    // [L]
-    float* smax = rstd + al4(L);       // [4L]
-    float* sinv = smax + H * L;        // [4L]
-    float* sdel = sinv + H * L;        // [4L]
-    float* demb = sdel + H * L;        // [vocab][32]
-    int* tok = reinterpret_cast<int*>(demb + dm.vocab * E);
-    float* nbuf = big;                 // n  [L][33]
-    float* df = big + L * SE;          // df [L][64]
-    load_weights(w, P, tid);
-    for (int i = tid; i < dm.vocab * E; i += NT) demb[i] = 0.f;
+    float* const e = sm + O_E;         // [L][33]   whole sample
+    float* const big = sm + O_BIG;     // [L][100]  qkv  | later n [L][33] + df [L][64] | later qkv again -> dk,dv in place
+    float* const o = sm + O_O;         // [L][33]   o    | later dq
+    float* const xh = sm + O_XH;       // [L][36]   r -> xhat (stride 33) | later dO, grad wrt attention output (stride 36)
+    float* const dn = sm + O_DN;       // [L][33]   dn -> dr -> de
+    float* const rstd = sm + O_RSTD;   // [L]
+    float* const smax = sm + O_SMAX;   // [4L]
+    float* const sinv = sm + O_SINV;   // [4L]
+    float* const sdel = sm + O_SDEL;   // [4L]
+    float* const redA = sm + O_REDA;   // [256] partial column sums (bias gradients), two buffers used alternately
+    float* const redB = sm + O_REDB;
+    int* const tok = reinterpret_cast<int*>(sm + O_TOK);   // [L]
+    int* const nxt = reinterpret_cast<int*>(sm + O_NXT);   // [L] occurrence chain: low 16 bits = 1 + next position with the
+                                       //     same code (0: none), bit 16 = this is the code's first occurrence in the string
+    float* const nbuf = big;               // n  [L][33]
+    float* const df = big + LMAX * SE;     // df [L][64]
+    load_weights(w, P, tid0);
 
-    const int c32 = tid & 31, g8 = tid >> 5;          // g8: column group 0..NG-1
-    constexpr int KPOS = (120 + NG - 1) / NG;
+    constexpr int KPOS = (120 + NG - 1) / NG;         // rows of dP (and (row, channel) items of a string) per thread
     float aPos[KPOS];
     // weight-gradient tiles (16x16, MFMA accumulators, persistent across strings): 8 of dW1 [64x32], 4 of dWo [32x32],
     // 12 of dWin [96x32].  Wave w owns tile w (accA); waves 0..7 also own dWin tile w+4 (accB).
     f32x4 accA = {0.f, 0.f, 0.f, 0.f}, accB = {0.f, 0.f, 0.f, 0.f};
-    const int wave = tid >> 6, lane = tid & 63;
     float a_b1 = 0.f, a_bo = 0.f, a_g = 0.f, a_b = 0.f, a_bin = 0.f;
 #pragma unroll
     for (int k = 0; k < KPOS; ++k) aPos[k] = 0.f;
     const float scale = 0.35355339059327373f;
     const size_t Kz = (size_t)dm.Lmax * F;
+    float* Sblk = slabs + (size_t)blockIdx.x * so.total;       // this block's partial slab (zeroed by the host memset)
+    const bool saved = dr.save != nullptr;
+#ifdef AFR_SHEET_TIMING
+    long long tacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast = wall_clock64();
+#endif
 
     for (int b = blockIdx.x; b < B; b += gridDim.x) {
-        // ---- recompute the forward chain
+        // Every per-thread LDS address below depends only on the thread id and L, i.e. is invariant across this loop; left
+        // alone the compiler hoists all of them out of it and spills >100 registers around every phase.  An opaque copy of
+        // the thread id per iteration keeps those values local to the phase that uses them.
+        int tid = tid0;
+        asm volatile("" : "+v"(tid));
+        const int c32 = tid & 31, g8 = tid >> 5, wave = tid >> 6, lane = tid & 63;     // g8: column group 0..NG-1
+        TMARK(11);
+        // ---- codes, then the embedded string; o and the softmax statistics come from the training forward
         ph_tokens(tok, x, ldx, b, L, dm.vocab, nullptr, tid);
-        __syncthreads();
-        ph_embed(e, tok, P, dr, b, L, tid);
-        __syncthreads();
-        const bool saved = dr.save != nullptr;
-        if (saved) {                                               // o and the softmax statistics come from the forward
+        if (saved) {
             const float* sv = dr.save + (size_t)b * L * 40;
             for (int i = tid; i < L * E; i += NT) o[(i >> 5) * SE + (i & 31)] = sv[i];
             for (int i = tid; i < H * L; i += NT) { smax[i] = sv[L * E + i]; sinv[i] = sv[L * E + H * L + i]; }
-        } else {
-            ph_inproj(big, e, w, L, tid);
-            __syncthreads();
-            ph_attention(o, big, dr, b, L, tid);
         }
         __syncthreads();
+        ph_embed(e, tok, P, dr, b, L, tid);
+        {   // occurrence chains of the codes (for the embedding gradient): 8 lanes per position
+            const int l = tid >> 3, k = tid & 7;
+            if (l < L) {
+                const int v = tok[l];
+                int nx = 0x7fff, pv = 0;
+                for (int m = l + 1 + k; m < L; m += 8) if (tok[m] == v) { nx = m; break; }
+                for (int m = l - 1 - k; m >= 0; m -= 8) if (tok[m] == v) { pv = 1; break; }
+                nx = min(nx, __shfl_xor(nx, 1, 64)); nx = min(nx, __shfl_xor(nx, 2, 64)); nx = min(nx, __shfl_xor(nx, 4, 64));
+                pv |= __shfl_xor(pv, 1, 64); pv |= __shfl_xor(pv, 2, 64); pv |= __shfl_xor(pv, 4, 64);
+                if (k == 0) nxt[l] = (nx == 0x7fff ? 0 : nx + 1) | (pv ? 0 : 1 << 16);
+            }
+        }
+        __syncthreads();
+        if (!saved) {                                              // no training forward ran: recompute o and the statistics
+            ph_inproj(big, e, w, L, tid);
+            __syncthreads();
+            ph_attention(o, big, dr, b, L, tid, smax, sinv);
+            __syncthreads();
+        }
+        TMARK(0);
         ph_outproj_res(xh, e, o, w, L, tid);
         __syncthreads();
         ph_layernorm(xh, nbuf, rstd, w, L, eps, tid);        // qkv dead: n overwrites the front of `big`
         __syncthreads();
+        TMARK(1);
         // ---- df = dz * dropout-mask * [pre>0]
         const T* dzr = dz + (size_t)b * Kz;
         for (int i = tid; i < L * F; i += NT) df[i] = (float)dzr[i] * fc_mask(dr, b, L, i);
         __syncthreads();
         lds_mma(nbuf, SE, 1, w.W1, SE, 1, L, F, E, tid, [&](int m, int j, float v) { if (!(v + w.b1[j] > 0.f)) df[m * F + j] = 0.f; });
         __syncthreads();
-        // ---- dW1 += df^T n (persistent MFMA tiles) ; db1 += sum df ; dn = df . W1
+        TMARK(2);
+        // ---- dW1 += df^T n (persistent MFMA tiles, waves 0-7) ; db1 partials (waves 12-15) ; dn = df . W1
         if (wave < 8) lds_mma_tile(accA, df, 1, F, nbuf, 1, SE, 16 * (wave >> 1), 16 * (wave & 1), L, lane);
-        if (tid < F) { float a = 0.f;
-_Pragma("clang loop unroll_count(4) vectorize(disable) interleave(disable)")
-            for (int l = 0; l < L; ++l) a += df[l * F + tid]; a_b1 += a; }
+        col_partials(redA, tid - 768, F, 4, L, [&](int l, int c) { return df[l * F + c]; });
         lds_mma(df, F, 1, w.W1, 1, SE, L, E, F, tid, [&](int m, int c, float v) { dn[m * SE + c] = v; });
         __syncthreads();
-        // ---- LayerNorm backward: dgamma, dbeta (column owners), then dr in place (row owners)
-        if (tid < E) { float a = 0.f;
-_Pragma("clang loop unroll_count(4) vectorize(disable) interleave(disable)")
-            for (int l = 0; l < L; ++l) a = fmaf(dn[l * SE + tid], xh[l * SE + tid], a); a_g += a; }
-        else if (tid < 2 * E) { const int c = tid - E; float a = 0.f;
-_Pragma("clang loop unroll_count(4) vectorize(disable) interleave(disable)")
-            for (int l = 0; l < L; ++l) a += dn[l * SE + c]; a_b += a; }
+        TMARK(3);
+        // ---- LayerNorm backward: dgamma, dbeta partials (4 row groups x 64 columns), then dr in place (8 lanes per row)
+        if (tid < F) a_b1 += col_total(redA, tid, F, 4);
+        col_partials(redB, tid, 2 * E, 4, L, [&](int l, int c) {
+            return c < E ? dn[l * SE + c] * xh[l * SE + c] : dn[l * SE + c - E]; });
         __syncthreads();
-        if (tid < L) {
-            float* row = dn + tid * SE;
-            const float* xr = xh + tid * SE;
-            float m1 = 0.f, m2 = 0.f;
-#pragma unroll 8
-            for (int c = 0; c < E; ++c) { const float gv = row[c] * w.lg[c]; m1 += gv; m2 = fmaf(gv, xr[c], m2); }
-            m1 *= (1.f / E); m2 *= (1.f / E);
-            const float rs = rstd[tid];
-#pragma unroll 8
-            for (int c = 0; c < E; ++c) row[c] = (row[c] * w.lg[c] - m1 - xr[c] * m2) * rs;
+        if (tid < E) a_g += col_total(redB, tid, 2 * E, 4);
+        else if (tid < 2 * E) a_b += col_total(redB, tid, 2 * E, 4);
+        {
+            const int l = tid >> 3, c0 = (tid & 7) * 4;
+            if (l < L) {
+                float* row = dn + l * SE + c0;
+                const float* xr = xh + l * SE + c0;
+                float gv[4], xv[4], m1 = 0.f, m2 = 0.f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { gv[j] = row[j] * w.lg[c0 + j]; xv[j] = xr[j]; m1 += gv[j]; m2 = fmaf(gv[j], xv[j], m2); }
+                m1 = sum8(m1) * (1.f / E); m2 = sum8(m2) * (1.f / E);
+                const float rs = rstd[l];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) row[j] = (gv[j] - m1 - xv[j] * m2) * rs;
+            }
         }
         __syncthreads();
-        // ---- out-proj backward: dWo += dr^T o ; dbo += sum dr ; dO = dr . Wo  (written over xhat, which is dead)
+        TMARK(4);
+        // ---- out-proj backward: dWo += dr^T o (waves 8-11) ; dbo partials (waves 0-1) ; dO = dr . Wo  (over xhat, which is dead)
         if (wave >= 8 && wave < 12) lds_mma_tile(accA, dn, 1, SE, o, 1, SE, 16 * ((wave - 8) >> 1), 16 * (wave & 1), L, lane);
-        if (tid < E) { float a = 0.f;
-_Pragma("clang loop unroll_count(4) vectorize(disable) interleave(disable)")
-            for (int l = 0; l < L; ++l) a += dn[l * SE + tid]; a_bo += a; }
+        col_partials(redA, tid, E, 4, L, [&](int l, int c) { return dn[l * SE + c]; });
         lds_mma(dn, SE, 1, w.Wo, 1, SE, L, E, E, tid, [&](int m, int c, float v) { xh[m * SD + c] = v; });
         __syncthreads();                                     // n, df dead; o dead after the dWo loop above
+        TMARK(5);
+        if (tid < E) a_bo += col_total(redA, tid, E, 4);
         ph_inproj(big, e, w, L, tid);                        // recompute qkv
         __syncthreads();
-        // ---- attention backward, by ROW: softmax stats, delta = sum_j dA.A, dq      (dq -> `o` buffer)
+        TMARK(6);
+        // ---- attention backward, by ROW: delta = sum_j dA.A, dq      (dq -> `o` buffer)
         //      two adjacent lanes per (head, query row): keys split even/odd, combined with xor-1 shuffles
         for (int rr = tid; rr < 2 * H * L; rr += NT) {
             const int r = rr >> 1, part = rr & 1;
@@ -356,18 +426,7 @@ _Pragma("clang loop unroll_count(4) vectorize(disable) interleave(disable)")
             ld8(xh + i * SD + h * D, dO);
 #pragma unroll
             for (int d = 0; d < D; ++d) q[d] *= scale;
-            float mx;
-            if (saved) {
-                mx = smax[r];
-            } else {
-                mx = -INFINITY;
-#pragma clang loop unroll_count(2) vectorize(disable) interleave(disable)
-                for (int j = part; j < L; j += 2) {
-                    ld8(big + j * SQ + E + h * D, kk);
-                    mx = fmaxf(mx, dot8(q, kk));
-                }
-                mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
-            }
+            const float mx = smax[r];
             // one pass for everything that depends on the softmax row: with p~ = exp(s - max) (unnormalised),
             //   sum = S p~ ,  num = S p~ dA ,  T1 = S p~ dA k_j ,  T2 = S p~ k_j     (dA = (dO.v_j) * dropout mask)
             // then  delta = num/sum  and  dq = scale * (T1 - delta * T2) / sum  ==  scale * S_j A_ij (dA_ij - delta) k_j
@@ -388,7 +447,7 @@ _Pragma("clang loop unroll_count(4) vectorize(disable) interleave(disable)")
             sum += __shfl_xor(sum, 1, 64);
             num += __shfl_xor(num, 1, 64);
             const float inv = 1.f / sum, delta = num * inv;
-            if (part == 0) { smax[r] = mx; sinv[r] = inv; sdel[r] = delta; }
+            if (part == 0) { sinv[r] = inv; sdel[r] = delta; }
 #pragma unroll
             for (int d = 0; d < D; ++d) {
                 const float a1 = t1[d] + __shfl_xor(t1[d], 1, 64);
@@ -397,6 +456,7 @@ _Pragma("clang loop unroll_count(4) vectorize(disable) interleave(disable)")
             }
         }
         __syncthreads();
+        TMARK(7);
         // ---- attention backward, by COLUMN: dk_j, dv_j; two lanes per (head, key), queries split even/odd.  The pair
         //      reads k_j, v_j into registers first and only then (after the shuffles) lane 0 overwrites them in place.
         for (int rr = tid; rr < 2 * H * L; rr += NT) {
@@ -428,8 +488,17 @@ _Pragma("clang loop unroll_count(4) vectorize(disable) interleave(disable)")
             }
         }
         __syncthreads();
-        // ---- in-proj backward: dWin += dqkv^T e ; dbin += sum dqkv ; de = dr + dqkv . Win   (de in place over dr)
-        //      dqkv lives in two places: dq in `o` (columns 0..31), dk|dv in `big` (columns 32..95)
+        TMARK(8);
+        // ---- in-proj backward: dWin += dqkv^T e ; dbin partials (waves 8-11) ; de = dr + dqkv . Win   (de in place over dr)
+        //      dqkv lives in two places: dq in `o` (columns 0..31), dk|dv in `big` (columns 32..95).
+        //      The slab words this string's embedding gradient will be added to are fetched now and used after the barrier.
+        float olde[KPOS];
+#pragma unroll
+        for (int k = 0; k < KPOS; ++k) {
+            const int i = tid + k * NT;
+            olde[k] = 0.f;
+            if (i < L * E && (nxt[i >> 5] >> 16)) olde[k] = Sblk[so.emb + tok[i >> 5] * E + (i & 31)];
+        }
         if (wave >= 12) {                                   // dWin tiles 0..3: rows j = 0..31 come from dq
             const int id = wave - 12;
             lds_mma_tile(accA, o, 1, SE, e, 1, SE, 16 * (id >> 1), 16 * (id & 1), L, lane);
@@ -437,31 +506,44 @@ _Pragma("clang loop unroll_count(4) vectorize(disable) interleave(disable)")
             const int id = wave + 4;
             lds_mma_tile(accB, big, 1, SQ, e, 1, SE, 16 * (id >> 1), 16 * (id & 1), L, lane);
         }
-        if (tid < QKV) { float a = 0.f;
-_Pragma("clang loop unroll_count(4) vectorize(disable) interleave(disable)")
-            for (int l = 0; l < L; ++l) a += dqkv_at(o, big, l, tid); a_bin += a; }
+        col_partials(redB, tid - 512, QKV, 2, L, [&](int l, int c) { return dqkv_at(o, big, l, c); });
         lds_mma(o, SE, 1, w.Win, 1, SE, L, E, E, tid, [&](int m, int c, float v) { dn[m * SE + c] += v; });
         lds_mma(big + E, SQ, 1, w.Win + E * SE, 1, SE, L, E, 2 * E, tid, [&](int m, int c, float v) { dn[m * SE + c] += v; });
         __syncthreads();
-        // ---- dP += de ; dEmb[tok] += de * embed-dropout-mask       (row v of dEmb owned by thread slot v%NG)
+        TMARK(9);
+        // ---- dP += de ; dEmb[code] += sum over the code's occurrences of de * embed-dropout-mask.  The (first occurrence,
+        //      channel) item owns the sum, walks the chain in position order and adds it to the block's slab in HBM/L2.
+        if (tid < QKV) a_bin += col_total(redB, tid, QKV, 2);
 #pragma unroll
         for (int k = 0; k < KPOS; ++k) { const int l = g8 + NG * k; if (l < L) aPos[k] += dn[l * SE + c32]; }
-#pragma clang loop unroll_count(4) vectorize(disable) interleave(disable)
-        for (int l = 0; l < L; ++l) {
-            const int v = tok[l];
-            if ((v & (NG - 1)) == g8) {
-                float m = 1.f;
-                if (dr.training) m = afr_keep((uint64_t)b * L * E + l * E + c32, dr.key_e, dr.thr_e) ? dr.sc_e : 0.f;
-                demb[v * E + c32] += dn[l * SE + c32] * m;
+#pragma unroll
+        for (int k = 0; k < KPOS; ++k) {
+            const int i = tid + k * NT;
+            if (i < L * E && (nxt[i >> 5] >> 16)) {
+                const int c = i & 31;
+                float sum = 0.f;
+                for (int m = i >> 5;;) {
+                    float mk = 1.f;
+                    if (dr.training) mk = afr_keep((uint64_t)b * L * E + m * E + c, dr.key_e, dr.thr_e) ? dr.sc_e : 0.f;
+                    sum += dn[m * SE + c] * mk;
+                    const int nn = nxt[m] & 0xffff;
+                    if (!nn) break;
+                    m = nn - 1;
+                }
+                Sblk[so.emb + tok[i >> 5] * E + c] = olde[k] + sum;
             }
         }
         __syncthreads();
     }
+    TMARK(10);
+#ifdef AFR_SHEET_TIMING
+    if (blockIdx.x == 0 && tid0 == 0) { printf("sheet_bwd phases (x10ns):"); for (int k = 0; k < 12; ++k) printf(" %lld", tacc[k]); printf("\n"); }
+#endif
     // ---- one partial slab per block, laid out like the flat parameter buffer (pads were zeroed by the host memset)
-    float* S = slabs + (size_t)blockIdx.x * so.total;
+    const int tid = tid0, c32 = tid & 31, g8 = tid >> 5, wave = tid >> 6, lane = tid & 63;
+    float* S = Sblk;
 #pragma unroll
     for (int k = 0; k < KPOS; ++k) { const int l = g8 + NG * k; if (l < L) S[so.pos + l * E + c32] = aPos[k]; }
-    for (int i = tid; i < dm.vocab * E; i += NT) S[so.emb + i] = demb[i];
     {   // MFMA D layout: row = 4*(lane>>4) + r, col = lane&15
         const int kq = lane >> 4, l15 = lane & 15;
 #pragma unroll
@@ -487,12 +569,8 @@ _Pragma("clang loop unroll_count(4) vectorize(disable) interleave(disable)")
 
 int afr_sheet_blocks(int B) { return B < 256 ? B : 256; }
 static inline int al4h(int n) { return (n + 3) & ~3; }
-size_t afr_sheet_fwd_lds_bytes(const SheetDims& d) {
-    return (size_t)(W_FLOATS + 4 * al4h(d.L * SE) + d.L * SQ + 2 * al4h(d.L) + 2 * H * d.L) * sizeof(float);
-}
-size_t afr_sheet_bwd_lds_bytes(const SheetDims& d) {
-    return (size_t)(W_FLOATS + 3 * al4h(d.L * SE) + d.L * SD + d.L * SQ + al4h(d.L) + 3 * H * d.L + d.vocab * E + d.L) * sizeof(float);
-}
+size_t afr_sheet_fwd_lds_bytes(const SheetDims& d) { return d.L <= LMAX ? (size_t)FWD_FLOATS * sizeof(float) : (size_t)-1; }
+size_t afr_sheet_bwd_lds_bytes(const SheetDims& d) { return d.L <= LMAX ? (size_t)BWD_FLOATS * sizeof(float) : (size_t)-1; }
 
 hipError_t afr_launch_sheet_fwd(int act_dtype, const SheetDims& d, const SheetParams& P, const SheetDrop& dr, const int64_t* x,
                                 int ldx, int B, void* z, float ln_eps, uint32_t* err_flag, hipStream_t s) {
