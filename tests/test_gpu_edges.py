@@ -141,3 +141,45 @@ def test_fused_optimizer_step_equals_unfused_step():
                 d = torch.cat([d[:E], d[2 * E:]])
             # the two kernels may contract the update's multiply-adds differently: last-bit differences only
             assert float(d.max()) <= 3e-6 * max(1.0, float(b.params[k].abs().max())), (dtype, k)
+
+
+# ----------------------------------------------------------------------------- glyph model: first-layer fold edge shapes
+def _glyph_check(cfg, B, dtype="f32", tol=1e-4, ytol=2e-5, xmax=None):
+    from .util import glyph_inputs
+    x, font, tu8 = glyph_inputs(cfg, B)
+    if xmax is not None:                                     # spread the codes over the whole vocabulary, repeats included
+        x = (np.arange(B, dtype=np.int64) * 7) % xmax
+    eng = _engine(cfg, dtype=dtype, max_batch=max(B, 8))
+    P = tparams(cfg)
+    rnd = oracle.bf16_round if dtype == "bf16" else None
+    xt, ft = torch.from_numpy(x), torch.from_numpy(font)
+    y = eng.forward(xt, ft if cfg.n_fonts else None).cpu().numpy()
+    yref, cache = oracle.glyph_forward(P, xt, ft, cfg, rnd=rnd)
+    assert maxabs(y, yref.numpy()) < ytol
+    lref, du = oracle.mse_loss_grad(cache["u"], torch.from_numpy(tu8.astype(np.float32) / 255.0))
+    Gref = oracle.glyph_backward(P, cache, (rnd or (lambda t: t))(du), cfg, rnd=rnd)
+    eng.train_step(xt, torch.from_numpy(tu8), font=ft if cfg.n_fonts else None, do_step=False)
+    assert abs(eng.read_loss() - float(lref)) < tol * float(lref)
+    for k, g in eng.grads.items():
+        ref = Gref[k].numpy()
+        assert maxabs(g.cpu().numpy(), ref) <= tol * max(1e-7, float(np.abs(ref).max())), k
+
+
+@pytest.mark.parametrize("cfg,B,xmax", [
+    (dict(hidden=(48,), out_h=4, out_w=6, n_fonts=0), 300, None),                 # no font table
+    (dict(hidden=(40, 24), out_h=4, out_w=4, n_fonts=3, vocab=100), 257, 100),    # vocab not a multiple of 8, every code used
+    (dict(hidden=(264,), out_h=4, out_w=6, n_fonts=1, embed_dim=64), 33, None),   # wider embedding, fc1 wider than one table tile
+    (dict(hidden=(16,), out_h=2, out_w=4, n_fonts=2), 1, None),                   # one glyph
+    (dict(hidden=(32,), out_h=4, out_w=4, n_fonts=2, vocab=600), 700, 600),       # table too wide to fold: plain gather + GEMM path
+    (dict(hidden=(), out_h=4, out_w=6, n_fonts=2), 64, None),                     # no hidden layer: embedding -> output
+])
+def test_glyph_first_layer_fold_edge_shapes(cfg, B, xmax):
+    """The glyph model's first Linear runs as a table gather (forward) and a one-hot-widened weight-gradient GEMM
+    (backward); shapes around its tile and staging sizes, and the two configurations that must NOT take that path."""
+    from .util import GlyphConfig
+    _glyph_check(GlyphConfig(**cfg), B, xmax=xmax)
+
+
+def test_glyph_fold_bf16_every_code_repeated():
+    from .util import GlyphConfig
+    _glyph_check(GlyphConfig(hidden=(64, 48), out_h=4, out_w=8, n_fonts=2), 1000, dtype="bf16", tol=3e-2, ytol=3e-2, xmax=128)
