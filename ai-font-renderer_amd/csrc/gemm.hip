@@ -516,30 +516,68 @@ __global__ __launch_bounds__(128 * WM, 2) void gemm_bf16(GemmParams p) {
             }
         }
     }
-    // fused AdamW operands run AD-1 passes ahead of their use (6 x 16 B per lane and pass).  The 4-wave kernel has the
-    // registers for three passes in flight (208 VGPRs at 2 waves/SIMD; measured 806 -> 777 us on R0), the 8-wave one not.
-#ifndef AFR_AD
-#define AFR_AD 4
-#endif
-    constexpr int AD = (WM == 2) ? AFR_AD : 2;
-    float4 adp[AD][2], adm[AD][2], adv[AD][2];
-    auto load_adam = [&](int ps, int buf) {
-        const int m = m0 + wm * 64 + ps * 8 + (lane >> 3);
-        if (m < p.M && ncol) {
-            const size_t wi = (size_t)m * p.ldc + n;
-            adp[buf][0] = ADLD(p.ad_p + wi); adp[buf][1] = ADLD(p.ad_p + wi + 4);
-            adm[buf][0] = ADLD(p.ad_m + wi); adm[buf][1] = ADLD(p.ad_m + wi + 4);
-            adv[buf][0] = ADLD(p.ad_v + wi); adv[buf][1] = ADLD(p.ad_v + wi + 4);
-        }
-    };
-    if (p.ad_p) {
+    if (!out_bf16) {
+        // f32 outputs (split-K slabs, direct gradients, fused AdamW): 16 lanes x 16 B cover one 64-column row, so every
+        // wave-instruction moves four whole 256-B row segments (with 8 columns per lane as below, an f32 row would be
+        // written and read as two interleaved half-filled passes over the same cache lines).  16 passes of 4 rows.
+        // Fused AdamW (weight-gradient GEMMs only): p, m, v of the wave's 64x64 tile are 16 passes x 3 x 16 B per lane.  Such a launch is
+        // bound by how many of those loads a CU keeps in flight (measured on R0: 770 / 745 / 726 / 713 us with 3 / 7 / 11 / 15
+        // passes ahead), so the 4-wave kernel (256 VGPRs per lane) keeps 13 of the 16 passes in flight from the moment the accumulators are parked
+        // in LDS.  (Issuing some before the K loop was slower: vmcnt is in-order, so the ring's counted waits then also wait
+        // for these HBM loads.)
+        constexpr bool ADAM = (ALAY == 1 && BLAY == 1);
+        constexpr int ADF = !ADAM ? 1 : (WM == 2) ? 14 : 4;    // 14: the deepest that allocates without scratch
+        const int c4 = lane & 15;
+        const int nf = n0 + wn * 64 + 4 * c4;
+        const bool okc = nf < p.N;
+        float4 qp[ADF], qm[ADF], qv[ADF];
+        auto load_f = [&](int ps, int buf) {
+            const int m = m0 + wm * 64 + ps * 4 + (lane >> 4);
+            if (m < p.M && okc) {
+                const size_t wi = (size_t)m * p.ldc + nf;
+                qp[buf] = ADLD(p.ad_p + wi); qm[buf] = ADLD(p.ad_m + wi); qv[buf] = ADLD(p.ad_v + wi);
+            }
+        };
+        const bool adam = ADAM && p.ad_p != nullptr;
+        if (adam) {
 #pragma unroll
-        for (int q = 0; q < AD - 1; ++q) load_adam(q, q);
+            for (int q = 0; q < ADF - 1; ++q) load_f(q, q);
+        }
+#pragma unroll
+        for (int ps = 0; ps < 16; ++ps) {
+            const int rl = ps * 4 + (lane >> 4);
+            if (adam && ps + ADF - 1 < 16) load_f(ps + ADF - 1, (ps + ADF - 1) % ADF);
+            f32x4 g = *reinterpret_cast<const f32x4*>(Wt + rl * 64 + ((c4 ^ (rl & 15)) << 2));
+            const int m = m0 + wm * 64 + rl;
+            if (m >= p.M || !okc) continue;
+            const size_t wi = (size_t)m * p.ldc + nf;
+            if (relu_mask) {                            // only the op-level API combines the mask with f32 output
+                const bf16x4 a = *reinterpret_cast<const bf16x4*>(aux + (size_t)m * p.ldaux + nf);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) g[r] = ((float)a[r] > 0.f) ? g[r] : 0.f;
+            }
+            if (adam) {
+                const int bf = ps % ADF;
+                float pp[4] = {qp[bf].x, qp[bf].y, qp[bf].z, qp[bf].w}, mm[4] = {qm[bf].x, qm[bf].y, qm[bf].z, qm[bf].w};
+                float vv[4] = {qv[bf].x, qv[bf].y, qv[bf].z, qv[bf].w};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) adamw_elem(pp[r], mm[r], vv[r], g[r], p.ad_decay, p.ad_b1, p.ad_b2, p.ad_eps, p.ad_step, p.ad_rsqrt_bc2);
+                ADST(p.ad_p + wi, make_float4(pp[0], pp[1], pp[2], pp[3]));
+                ADST(p.ad_m + wi, make_float4(mm[0], mm[1], mm[2], mm[3]));
+                ADST(p.ad_v + wi, make_float4(vv[0], vv[1], vv[2], vv[3]));
+                if (p.ad_shadow) {
+                    bf16x4 o = {(bf16_t)pp[0], (bf16_t)pp[1], (bf16_t)pp[2], (bf16_t)pp[3]};
+                    __builtin_nontemporal_store(o, reinterpret_cast<bf16x4*>(p.ad_shadow + wi));
+                }
+            } else {
+                nt_st4(Cf + wi, make_float4(g[0], g[1], g[2], g[3]));
+            }
+        }
+        return;
     }
 #pragma unroll
     for (int ps = 0; ps < 8; ++ps) {
         const int rl = ps * 8 + (lane >> 3);
-        if (p.ad_p && ps + AD - 1 < 8) load_adam(ps + AD - 1, (ps + AD - 1) % AD);
         const f32x4 lo = *reinterpret_cast<const f32x4*>(Wt + rl * 64 + (((2 * c8) ^ (rl & 15)) << 2));
         const f32x4 hi = *reinterpret_cast<const f32x4*>(Wt + rl * 64 + (((2 * c8 + 1) ^ (rl & 15)) << 2));
         float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
@@ -569,36 +607,13 @@ __global__ __launch_bounds__(128 * WM, 2) void gemm_bf16(GemmParams p) {
                 v[r] = (u >= 0.f && u <= 1.f) ? g2 * diff : 0.f;
             }
         }
-        if (p.ad_p) {                                  // fused AdamW: v[] is the gradient of weight elements (m, n..n+7)
-            const size_t wi = (size_t)m * p.ldc + n;
-            const int bf = ps % AD;
-            float pp[8] = {adp[bf][0].x, adp[bf][0].y, adp[bf][0].z, adp[bf][0].w, adp[bf][1].x, adp[bf][1].y, adp[bf][1].z, adp[bf][1].w};
-            float mm[8] = {adm[bf][0].x, adm[bf][0].y, adm[bf][0].z, adm[bf][0].w, adm[bf][1].x, adm[bf][1].y, adm[bf][1].z, adm[bf][1].w};
-            float vv[8] = {adv[bf][0].x, adv[bf][0].y, adv[bf][0].z, adv[bf][0].w, adv[bf][1].x, adv[bf][1].y, adv[bf][1].z, adv[bf][1].w};
-#pragma unroll
-            for (int r = 0; r < 8; ++r) adamw_elem(pp[r], mm[r], vv[r], v[r], p.ad_decay, p.ad_b1, p.ad_b2, p.ad_eps, p.ad_step, p.ad_rsqrt_bc2);
-            ADST(p.ad_p + wi, make_float4(pp[0], pp[1], pp[2], pp[3]));
-            ADST(p.ad_p + wi + 4, make_float4(pp[4], pp[5], pp[6], pp[7]));
-            ADST(p.ad_m + wi, make_float4(mm[0], mm[1], mm[2], mm[3]));
-            ADST(p.ad_m + wi + 4, make_float4(mm[4], mm[5], mm[6], mm[7]));
-            ADST(p.ad_v + wi, make_float4(vv[0], vv[1], vv[2], vv[3]));
-            ADST(p.ad_v + wi + 4, make_float4(vv[4], vv[5], vv[6], vv[7]));
-            if (p.ad_shadow) {
-                bf16x8 o;
-#pragma unroll
-                for (int r = 0; r < 8; ++r) o[r] = (bf16_t)pp[r];
-                *reinterpret_cast<bf16x8*>(p.ad_shadow + wi) = o;
-            }
-        } else if (out_bf16) {
+        {
             bf16x8 o;
 #pragma unroll
             for (int r = 0; r < 8; ++r) o[r] = (bf16_t)v[r];
             // streaming stores: a kernel's dirty L2 lines are written back at its end, before the next kernel may start
             // (the XCDs' L2s are not coherent with each other); write-through output leaves nothing to drain (C3 -3.7 %)
             __builtin_nontemporal_store(o, reinterpret_cast<bf16x8*>(Cb + (size_t)m * p.ldc + n));
-        } else {
-            nt_st4(Cf + (size_t)m * p.ldc + n, make_float4(v[0], v[1], v[2], v[3]));
-            nt_st4(Cf + (size_t)m * p.ldc + n + 4, make_float4(v[4], v[5], v[6], v[7]));
         }
     }
     if (mse) {
