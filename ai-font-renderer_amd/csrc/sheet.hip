@@ -218,7 +218,7 @@ template <typename T>
 __global__ __launch_bounds__(NT) void sheet_fwd_kernel(SheetDims dm, SheetParams P, SheetDrop dr, const int64_t* __restrict__ x,
                                                         int ldx, int B, T* __restrict__ z, float eps, uint32_t* err) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    const int tid = threadIdx.x, L = dm.L;
+    const int tid0 = threadIdx.x, L = dm.L;
     const Wts w = carve_weights(sm);
     float* const e = sm + F_E;
     float* const qkv = sm + F_QKV;
@@ -229,9 +229,11 @@ __global__ __launch_bounds__(NT) void sheet_fwd_kernel(SheetDims dm, SheetParams
     float* const smax = sm + F_SMAX;   // [4L]
     float* const sinv = sm + F_SINV;   // [4L]
     int* const tok = reinterpret_cast<int*>(sm + F_TOK);
-    load_weights(w, P, tid);
+    load_weights(w, P, tid0);
     const size_t Kz = (size_t)dm.Lmax * F;
     for (int b = blockIdx.x; b < B; b += gridDim.x) {
+        int tid = tid0;                                             // opaque per iteration: see sheet_bwd_kernel
+        asm volatile("" : "+v"(tid));
         ph_tokens(tok, x, ldx, b, L, dm.vocab, err, tid);
         __syncthreads();
         ph_embed(e, tok, P, dr, b, L, tid);
