@@ -635,8 +635,7 @@ __global__ __launch_bounds__(128 * WM, 2) void gemm_bf16(GemmParams p) {
 static bool bf16_use_wide(const GemmParams& p) {
     // a fused-AdamW epilogue moves 26 B per output element and is the longer half of such a kernel; two 128x128 blocks
     // per CU (64 KiB of LDS each) let one block's epilogue run under the other's K loop, one 256x128 block cannot
-    static const int wide_adam = getenv("AFR_ADAM_WIDE") ? atoi(getenv("AFR_ADAM_WIDE")) : 0;
-    if (p.ad_p && !wide_adam) return false;
+    if (p.ad_p) return false;
     const long long t = (long long)((p.M + 255) / 256) * ((p.N + 127) / 128) * p.splitk;
     return t >= 192 && p.K / p.splitk >= 256;      // the 3-stage ring needs a few K-tiles to pay
 }
