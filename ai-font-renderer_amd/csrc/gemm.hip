@@ -37,7 +37,11 @@ __device__ __forceinline__ void tile_of_block(const GemmParams& p, int BM, int B
     const int t = v - z * tiles;
     const bool n_slow = p.N > p.M;                   // the slow (grouped) dimension is the larger operand's
     const int ts = n_slow ? tiles_n : tiles_m, tf = n_slow ? tiles_m : tiles_n;
-    constexpr int G = 8;
+    // 8 slow tiles per group, or fewer when that makes an XCD's contiguous range exactly one group: then the group's
+    // slow-operand tiles enter ONE L2 (C3 forward: 8192x1024 output = 32x8 tiles, 32 per XCD -> groups of 4x8; with
+    // groups of 8x8 two XCDs shared each group and the 16 MB activation operand was fetched twice)
+    int G = 8;
+    if (r == 0 && q % tf == 0 && q / tf >= 1 && q / tf < 8 && tiles % q == 0) G = q / tf;
     const int grp = t / (G * tf);
     const int s0 = grp * G;
     const int gs = min(G, ts - s0);
