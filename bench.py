@@ -68,7 +68,7 @@ def host_cores():
     return int(os.environ.get("AFR_CPU_THREADS", min(n, 16)))
 
 
-def cpu_baseline(name, cfg, B, budget_s=15.0):
+def cpu_baseline(name, cfg, B, budget_s=12.0):
     """The oracle (a CPU port of the reference's step in plain torch ops) timed on this box's host cores."""
     from oracle import afr_oracle as oracle            # checker / baseline only -- never on the product path
     cores = host_cores()
@@ -91,8 +91,8 @@ def cpu_baseline(name, cfg, B, budget_s=15.0):
         step += 1
         if step > 1:
             times.append(dt)                                          # first step is warm-up
-        if (time.perf_counter() - t_start > budget_s and len(times) >= 2) or len(times) >= 20:
-            break
+        if (time.perf_counter() - t_start > budget_s and len(times) >= 2) or len(times) >= 400:
+            break                                                     # ~12 s of CPU work (at least 2 timed steps)
     med = float(np.median(times))
     return {"value": B / med, "unit": "glyphs/s", "cores": cores, "kind": "port",
             "sample": f"{len(times)} steps of batch {B} after 1 warm-up, median step {med * 1e3:.1f} ms, fp32, torch {torch.__version__} CPU ops"}
