@@ -467,8 +467,13 @@ hipError_t afr_launch_glyph_l1_fwd(int act_dtype, const float* emb, const float*
     if ((N1 & 7) || (E & 7)) return hipErrorInvalidValue;
     const int K0 = afr_glyph_k0(E, vocab, n_fonts);
     const int rows = vocab + n_fonts;
-    hipLaunchKernelGGL(glyph_table_kernel, dim3((rows + GT_ROWS - 1) / GT_ROWS, (N1 + 255) / 256), dim3(256),
-                       (256 * (E + 1) + GT_ROWS * E) * sizeof(float), s, emb, font_emb, W1, vocab, rows, E, N1, table);
+    const size_t tlds = (size_t)(256 * (E + 1) + GT_ROWS * E) * sizeof(float);      // 35 KB at E = 32, 136 KB at the E = 128 limit
+    if (tlds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)glyph_table_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tlds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(glyph_table_kernel, dim3((rows + GT_ROWS - 1) / GT_ROWS, (N1 + 255) / 256), dim3(256), tlds, s, emb, font_emb,
+                       W1, vocab, rows, E, N1, table);
     dim3 g(grid_for((long long)B * ((N1 + K0) / 8), 256, 8192)), b(256);
     if (act_dtype == AFR_BF16)
         hipLaunchKernelGGL(glyph_l1_fwd_kernel<bf16_t>, g, b, 0, s, table, b1, emb, font_emb, x, font, B, E, N1, vocab, n_fonts, K0,

@@ -169,6 +169,7 @@ def _glyph_check(cfg, B, dtype="f32", tol=1e-4, ytol=2e-5, xmax=None):
     (dict(hidden=(48,), out_h=4, out_w=6, n_fonts=0), 300, None),                 # no font table
     (dict(hidden=(40, 24), out_h=4, out_w=4, n_fonts=3, vocab=100), 257, 100),    # vocab not a multiple of 8, every code used
     (dict(hidden=(264,), out_h=4, out_w=6, n_fonts=1, embed_dim=64), 33, None),   # wider embedding, fc1 wider than one table tile
+    (dict(hidden=(24,), out_h=2, out_w=4, n_fonts=1, embed_dim=128), 40, None),   # widest embedding the table kernel stages (136 KB of LDS)
     (dict(hidden=(16,), out_h=2, out_w=4, n_fonts=2), 1, None),                   # one glyph
     (dict(hidden=(32,), out_h=4, out_w=4, n_fonts=2, vocab=600), 700, 600),       # table too wide to fold: plain gather + GEMM path
     (dict(hidden=(), out_h=4, out_w=6, n_fonts=2), 64, None),                     # no hidden layer: embedding -> output
