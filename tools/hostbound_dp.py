@@ -34,6 +34,37 @@ def onear():
     dist.all_reduce(eng.flat_grads)
     eng.adamw_step()
 print('staged-one-blocking-allreduce host/wall us', timeit(onear))
+def two_blocking():
+    eng.forward_loss(x, t, font=font, mean_elems=me)
+    first = eng.backward_stage(0)
+    dist.all_reduce(first)
+    for s in range(1, eng.backward_stages): eng.backward_stage(s)
+    dist.all_reduce(eng.flat_grads[:first.storage_offset()])
+    eng.adamw_step()
+print('staged-two-blocking-allreduces host/wall us', timeit(two_blocking))
+def two_async_late_wait():
+    eng.forward_loss(x, t, font=font, mean_elems=me)
+    first = eng.backward_stage(0)
+    w1 = dist.all_reduce(first, async_op=True)
+    for s in range(1, eng.backward_stages): eng.backward_stage(s)
+    w2 = dist.all_reduce(eng.flat_grads[:first.storage_offset()], async_op=True)
+    w1.wait(); w2.wait()
+    eng.adamw_step()
+print('staged-two-async host/wall us', timeit(two_async_late_wait))
+comm = torch.cuda.Stream()
+def two_side_stream():
+    cur = torch.cuda.current_stream()
+    eng.forward_loss(x, t, font=font, mean_elems=me)
+    first = eng.backward_stage(0)
+    ev = torch.cuda.Event(); ev.record(cur)
+    with torch.cuda.stream(comm):
+        comm.wait_event(ev)
+        dist.all_reduce(first)                     # "blocking" only for the side stream
+    for s in range(1, eng.backward_stages): eng.backward_stage(s)
+    dist.all_reduce(eng.flat_grads[:first.storage_offset()])
+    cur.wait_stream(comm)
+    eng.adamw_step()
+print('staged-two-collectives-side-stream host/wall us', timeit(two_side_stream))
 def mono():
     eng.train_step(x, t, font=font, mean_elems=me, do_step=False)
     dist.all_reduce(eng.flat_grads)
