@@ -641,7 +641,9 @@ static bool bf16_use_wide(const GemmParams& p) {
     // per CU (64 KiB of LDS each) let one block's epilogue run under the other's K loop, one 256x128 block cannot
     if (p.ad_p) return false;
     const long long t = (long long)((p.M + 255) / 256) * ((p.N + 127) / 128) * p.splitk;
-    return t >= 192 && p.K / p.splitk >= 256;      // the 3-stage ring needs a few K-tiles to pay
+    // a wide grid that leaves CUs idle loses to the 128x128 kernel at two blocks per CU (R0 dX: 200 wide tiles 323 us,
+    // 400 narrow ones 302 us); from a full round on the two run level and wide needs fewer L2->LDS bytes
+    return t >= 232 && p.K / p.splitk >= 256;      // the 3-stage ring needs a few K-tiles to pay
 }
 // the symbol rocprofv3 will report for this launch (without the "void bf16k::" decoration)
 const char* afr_gemm_kernel_name(int dtype, const GemmParams& p) {
