@@ -121,6 +121,29 @@ def test_reference_batch_r0_full_size_linearity_and_tail_batches():
     assert float((acc - full).abs().max()) < 1e-4 * float(full.abs().max())
 
 
+def test_reference_batch_r0_full_size_bf16_with_dropout_tracks_the_f32_engine():
+    """Throughput mode at the reference's full batch (1024 sheets, all three dropouts active): bitwise reproducible, and
+    loss / gradients stay within bf16 rounding of the exact-f32 engine run on the same counter-hash masks."""
+    B = 1024
+    x = torch.from_numpy(synth.encode_strings(synth.dataset_strings(B), 100)).cuda()
+    t = torch.from_numpy(synth.synth_sheet_targets(B, 80, 240, tensor_id=974)).cuda()
+    res = {}
+    for dtype in ("f32", "bf16"):
+        eng = _engine(R0, dtype=dtype, max_batch=B, with_optimizer=False)
+        eng.train_step(x, t, step=7, do_step=False)
+        g, l = eng.flat_grads.clone(), eng.read_loss()
+        eng.train_step(x, t, step=7, do_step=False)
+        assert torch.equal(eng.flat_grads, g) and eng.read_loss() == l, dtype
+        res[dtype] = (l, {k: v.clone() for k, v in eng.grads.items()})
+        del eng
+        torch.cuda.empty_cache()
+    assert abs(res["bf16"][0] - res["f32"][0]) < 2e-3 * res["f32"][0]
+    for k, ref in res["f32"][1].items():
+        got = res["bf16"][1][k]
+        rel = float((got - ref).norm() / ref.norm().clamp_min(1e-12))
+        assert rel < 5e-2, (k, rel)
+
+
 def test_fused_optimizer_step_equals_unfused_step():
     """afr_train_step fuses AdamW of fc_output.weight into its dW GEMM; the result must equal backward + afr_adamw_step."""
     from .util import SheetConfig
