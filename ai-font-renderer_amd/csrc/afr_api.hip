@@ -591,7 +591,7 @@ static int backward_stage_impl(afr_plan* p, int stage, int64_t* g_off, int64_t* 
         SheetSlabOff so{(int)p->s_pos, (int)p->s_emb, (int)p->s_win, (int)p->s_bin, (int)p->s_wo, (int)p->s_bo, (int)p->s_g,
                         (int)p->s_b, (int)p->s_w1, (int)p->s_b1, (int)p->s_wout};
         {
-            ProfScope ps(p, s, "sheet_bwd", 9.0e6 * B, 0.0);       // recompute + reverse: ~9 MFLOP of f32 VALU work per string
+            ProfScope ps(p, s, "sheet_bwd", 7.0e6 * B, 0.0);       // partial recompute + reverse: ~7 MFLOP of f32 work per string
             HIPCHK(afr_launch_sheet_bwd(c.dtype, d, sheet_params(p), make_drop(p, p->last_training, p->last_step), p->last_x,
                                         p->last_ldx, B, dz, c.ln_eps, slabs, so, s));
         }

@@ -3,16 +3,19 @@
 // Forward (reference model.py:167-193): embedding gather -> dropout -> + learned positions -> packed in-proj ->
 // 4-head 100x100 softmax attention (dropout on the probabilities) -> out-proj -> residual + LayerNorm ->
 // fc1 + ReLU + dropout -> flattened (zero-padded) feature row z[b][max_length*64], the A operand of fc_output.
-// Backward (model.py:309) recomputes that chain in LDS from the same counter-hash dropout stream instead of
-// saving activations (a sample's whole state is <100 KB of LDS), then walks it in reverse.
+// Backward (model.py:309) rebuilds that chain in LDS -- the attention output and softmax row statistics come from the
+// training forward (16 KB per string), everything else is recomputed from the same counter-hash dropout stream -- and
+// then walks it in reverse (a sample's whole state is < 150 KB of LDS).
 //
 // One 1024-thread workgroup owns one string at a time and loops over strings (persistent grid, <= 256 blocks):
 // weights are loaded into LDS once.  The small matmuls (in-proj, out-proj, fc1 and their data/weight gradients) run on
-// the matrix cores straight from LDS (exact-f32 v_mfma_f32_16x16x4_f32); the 100x100 attention stays on the VALU.  Every reduction has a single owner thread and a fixed order -- no atomics:
-//   * attention backward is split by ROW (softmax statistics, delta, dq) and then by COLUMN (dk, dv), each
-//     recomputing the scores it needs, so dv/dk need no scatter;
-//   * the 10 small parameter gradients accumulate across the block's strings in registers (dEmb in LDS, row v
-//     owned by thread slot v%32) and leave as one partial slab per block, summed in block order by reduce_slabs.
+// the matrix cores straight from LDS (exact-f32 v_mfma_f32_16x16x4_f32); the 100x100 attention stays on the VALU.
+// Every reduction has a single owner thread and a fixed order -- no atomics:
+//   * attention backward is split by ROW (delta, dq) and then by COLUMN (dk, dv), each recomputing the scores it
+//     needs, so dv/dk need no scatter;
+//   * the small parameter gradients accumulate across the block's strings in registers / MFMA accumulators; the
+//     embedding gradient follows each code's occurrence chain and is added to the block's slab in L2; every block
+//     leaves one partial slab, summed in block order by the grouped reduce.
 // E=32, 4 heads of 8, fc1 width 64 are compile-time (the reference hard-codes them: model.py:79,81,148).
 #include "afr_common.h"
 #include "../../include/afr.h"
