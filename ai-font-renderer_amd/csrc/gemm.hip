@@ -373,6 +373,40 @@ __global__ __launch_bounds__(128 * WM, 2) void gemm_bf16(GemmParams p) {
         for (int i = 0; i < 4; ++i) { asm volatile("" ::"v"(fa[i])); asm volatile("" ::"v"(fb[i])); }
 #endif
     };
+    // k-step-1 MFMAs of tile t with the refill of the freed slot (tile t+3) and the fragment reads of tile t+1 (k-step 0)
+    // issued BETWEEN the rows of MFMAs instead of ahead of them: the memory instructions go out while the matrix pipe works.
+    auto stage_piece = [&](int t, int slot, int q) {
+        const unsigned S = lds0 + slot * STAGE_BYTES;
+        const int k0 = kbeg + t * BK;
+        if (q < A_PER_WAVE) {
+            const int g = wave * A_PER_WAVE + q;
+            const int sub = g >> 4;
+            stage_inst<ALAY>(rA, S + sub * SUB, p.lda, p.M, m0 + sub * 128, k0, kend, g & 15, lane);
+        } else {
+            stage_inst<BLAY>(rB, S + ASUB * SUB, p.ldb, p.N, n0, k0, kend, wave * B_PER_WAVE + (q - A_PER_WAVE), lane);
+        }
+    };
+    auto mma_mem = [&](const bf16x8 (&fa)[4], const bf16x8 (&fb)[4], bool do_stage, int tn, int slot, bool do_read, const char* Sn,
+                       bf16x8 (&ra)[4], bf16x8 (&rb)[4]) {
+        constexpr int NP = A_PER_WAVE + B_PER_WAVE;
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+            if (do_stage) {
+#pragma unroll
+                for (int q = i * NP / 4; q < (i + 1) * NP / 4; ++q) stage_piece(tn, slot, q);
+            }
+            if (do_read) {
+                ra[i] = read_frag<ALAY>(Sn + (wm >> 1) * SUB, (wm & 1) * 64 + 16 * i, 0, lane);
+                rb[i] = read_frag<BLAY>(Sn + ASUB * SUB, wn * 64 + 16 * i, 0, lane);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __builtin_amdgcn_s_setprio(0);
+    };
     // fused bias gradient: column sums of the k-strided A tile [64 k][BM x].  A thread owns one 16-byte chunk (8
     // consecutive x) and walks 4 of the 64 k-rows; 16 threads share a chunk and are combined once after the K loop.
     constexpr int CH = BM / 8;                       // chunks per k-row; NTHR / CH == 16 row groups
@@ -397,8 +431,8 @@ __global__ __launch_bounds__(128 * WM, 2) void gemm_bf16(GemmParams p) {
         //   A  issues the LDS reads of k-step 1 of tile t          B  runs the MFMAs of k-step 0 (fragments read earlier)
         //   C  waits until the DMA of tile t+1 has landed (tile t+2 stays in flight: counted vmcnt) and meets the
         //      other waves at the one barrier of the tile; every wave's reads of tile t are complete by then
-        //   D  re-fills the freed slot with tile t+3                E  issues the reads of k-step 0 of tile t+1
-        //   F  runs the MFMAs of k-step 1
+        //   F  runs the MFMAs of k-step 1 and, between its rows of MFMAs (mma_mem), D re-fills the freed slot with tile
+        //      t+3 and E issues the reads of k-step 0 of tile t+1 (+2..7 % over issuing D and E ahead of F)
         // so every MFMA block has the next block's LDS reads in flight under it, and two tiles of DMA are in flight.
 #pragma unroll
         for (int t = 0; t < 3; ++t)
@@ -420,15 +454,13 @@ __global__ __launch_bounds__(128 * WM, 2) void gemm_bf16(GemmParams p) {
                 if (t + 2 < nt) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");   // C
                 else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
-#ifndef AFR_ABLATE_NOLOAD
-                if (t + 3 < nt) stage(t + 3, slot);                               // D
-#endif
                 int ns = slot + 1; if (ns == 3) ns = 0;
-                const char* Sn = smem + ns * STAGE_BYTES;
-                read_a(Sn, 0, a0); read_b(Sn, 0, b0);                             // E
+                mma_mem(a1, b1, t + 3 < nt, t + 3, slot, true, smem + ns * STAGE_BYTES, a0, b0);   // D, E inside F
                 slot = ns;
+            } else {
+                mma(a1, b1);
             }
-            mma(a1, b1);                                                          // F
+
         }
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
