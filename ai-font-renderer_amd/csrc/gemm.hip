@@ -387,7 +387,7 @@ __global__ __launch_bounds__(128 * WM, 2) void gemm_bf16(GemmParams p) {
         }
     };
     auto mma_mem = [&](const bf16x8 (&fa)[4], const bf16x8 (&fb)[4], bool do_stage, int tn, int slot, bool do_read, const char* Sn,
-                       bf16x8 (&ra)[4], bf16x8 (&rb)[4]) {
+                       int ks, bf16x8 (&ra)[4], bf16x8 (&rb)[4]) {
         constexpr int NP = A_PER_WAVE + B_PER_WAVE;
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -400,8 +400,8 @@ __global__ __launch_bounds__(128 * WM, 2) void gemm_bf16(GemmParams p) {
                 for (int q = i * NP / 4; q < (i + 1) * NP / 4; ++q) stage_piece(tn, slot, q);
             }
             if (do_read) {
-                ra[i] = read_frag<ALAY>(Sn + (wm >> 1) * SUB, (wm & 1) * 64 + 16 * i, 0, lane);
-                rb[i] = read_frag<BLAY>(Sn + ASUB * SUB, wn * 64 + 16 * i, 0, lane);
+                ra[i] = read_frag<ALAY>(Sn + (wm >> 1) * SUB, (wm & 1) * 64 + 16 * i, ks, lane);
+                rb[i] = read_frag<BLAY>(Sn + ASUB * SUB, wn * 64 + 16 * i, ks, lane);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -428,7 +428,8 @@ __global__ __launch_bounds__(128 * WM, 2) void gemm_bf16(GemmParams p) {
 
     if (STAGES == 3) {
         // Software-pipelined ring.  Per K-tile t (slot t%3), each wave:
-        //   A  issues the LDS reads of k-step 1 of tile t          B  runs the MFMAs of k-step 0 (fragments read earlier)
+        //   B  runs the MFMAs of k-step 0 (fragments read earlier) and, between its rows of MFMAs, A issues the LDS reads
+        //      of k-step 1 of tile t
         //   C  waits until the DMA of tile t+1 has landed (tile t+2 stays in flight: counted vmcnt) and meets the
         //      other waves at the one barrier of the tile; every wave's reads of tile t are complete by then
         //   F  runs the MFMAs of k-step 1 and, between its rows of MFMAs (mma_mem), D re-fills the freed slot with tile
@@ -447,15 +448,14 @@ __global__ __launch_bounds__(128 * WM, 2) void gemm_bf16(GemmParams p) {
         int slot = 0;
         for (int t = 0; t < nt; ++t) {
             const char* S = smem + slot * STAGE_BYTES;
-            read_a(S, 1, a1); read_b(S, 1, b1);                                  // A
             if (ALAY == 1 && do_cs) colsum_tile(S);
-            mma(a0, b0);                                                          // B
+            mma_mem(a0, b0, false, 0, 0, true, S, 1, a1, b1);                     // A inside B
             if (t + 1 < nt) {
                 if (t + 2 < nt) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");   // C
                 else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
                 int ns = slot + 1; if (ns == 3) ns = 0;
-                mma_mem(a1, b1, t + 3 < nt, t + 3, slot, true, smem + ns * STAGE_BYTES, a0, b0);   // D, E inside F
+                mma_mem(a1, b1, t + 3 < nt, t + 3, slot, true, smem + ns * STAGE_BYTES, 0, a0, b0);   // D, E inside F
                 slot = ns;
             } else {
                 mma(a1, b1);
