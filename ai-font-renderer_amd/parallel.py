@@ -13,6 +13,9 @@ each rank draws its own dropout stream (rank is part of the counter-hash key).
 `engine` is anything with train_step(x, target, font=, mean_elems=, do_step=), flat_grads, adamw_step(**hyper)
 and loss_accum: the HIP Engine in production; tests drive the same logic on CPU (gloo) with a stand-in.
 """
+import os
+
+import torch
 
 
 def shard_rows(n_rows, rank, world):
@@ -26,6 +29,10 @@ def shard_rows(n_rows, rank, world):
 # schedule costs ~33 us of staging and cross-stream hand-offs per step (measured with a world of one on the 8.5 MB C3
 # model: 274 us against 240 us), more than the transfer time it could hide.  The sheet model (492 MB) overlaps.
 OVERLAP_MIN_BYTES = 64 << 20
+# AFR_DP_GRAD_BF16=1 (opt-in, throughput mode only): exchange the gradients as bf16 -- half the bytes on the xGMI links
+# at the price of rounding each rank's gradient to 8 significant bits before the sum (the exact-f32 exchange is the default
+# and what the data-parallel tests pin).  Meant for link-bound small models; unmeasured on a multi-GPU node so far.
+GRAD_BF16 = os.environ.get("AFR_DP_GRAD_BF16") == "1"
 
 
 class DataParallelStepper:
@@ -57,7 +64,12 @@ class DataParallelStepper:
             work.wait()
         else:
             eng.train_step(x, target, font=font, mean_elems=mean_elems, do_step=False, **hyper)
-            self.dist.all_reduce(eng.flat_grads)              # sum over ranks; RCCL ring/tree over xGMI
+            if GRAD_BF16 and getattr(eng, "dtype", "f32") == "bf16":
+                g16 = eng.flat_grads.to(torch.bfloat16)
+                self.dist.all_reduce(g16)
+                eng.flat_grads.copy_(g16)
+            else:
+                self.dist.all_reduce(eng.flat_grads)          # sum over ranks; RCCL ring/tree over xGMI
         eng.adamw_step(**opt)
 
     def global_loss(self, reset=True):

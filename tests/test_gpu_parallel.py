@@ -82,3 +82,36 @@ def test_data_parallel_stepper_over_rccl_world1(schedule, monkeypatch):
         assert torch.equal(eng2.flat_params, p_dp)
     finally:
         dist.destroy_process_group()
+
+
+def test_opt_in_bf16_gradient_exchange_tracks_the_exact_exchange(monkeypatch):
+    """AFR_DP_GRAD_BF16=1 rounds each rank's gradient to bf16 for the all-reduce (throughput mode only): three steps stay
+    within bf16 rounding of the exact-f32 exchange; the f32 engine ignores the switch."""
+    import torch.distributed as dist
+    from ai_font_renderer_amd import parallel
+    from ai_font_renderer_amd.parallel import DataParallelStepper
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", str(29600 + os.getpid() % 300))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        outs = {}
+        for flag in (False, True):
+            monkeypatch.setattr(parallel, "GRAD_BF16", flag)
+            cfg, eng = _glyph_engine(dtype="bf16")
+            x, font, t = glyph_inputs(cfg, 300)
+            xt, ft, tt = torch.from_numpy(x).cuda(), torch.from_numpy(font).cuda(), torch.from_numpy(t).cuda()
+            st = DataParallelStepper(eng, dist, world=2)
+            for _ in range(3):
+                st.step(xt, tt, ft, mean_elems=300 * cfg.pixels)
+            outs[flag] = eng.flat_params.clone()
+        rel = float((outs[True] - outs[False]).norm() / outs[False].norm())
+        assert 0 < rel < 2e-3, rel
+        monkeypatch.setattr(parallel, "GRAD_BF16", True)
+        cfg, eng = _glyph_engine(dtype="f32")
+        st = DataParallelStepper(eng, dist, world=2)
+        st.step(xt, tt, ft, mean_elems=300 * cfg.pixels)
+        cfg2, eng2 = _glyph_engine(dtype="f32")
+        DataParallelStepper(eng2, None, 1).step(xt, tt, ft, mean_elems=300 * cfg.pixels)
+        assert torch.equal(eng.flat_params, eng2.flat_params)
+    finally:
+        dist.destroy_process_group()
