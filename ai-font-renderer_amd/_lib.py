@@ -74,6 +74,10 @@ def load(path=LIB_PATH):
         raise ImportError(
             f"{path} is missing: the HIP extension is the only implementation of the hot path "
             "(no CPU fallback).  Build it with ai-font-renderer_amd/csrc/build.sh or __graft_entry__.build().")
+    # torch first: it ships its own libamdhip64, and libafr.so must bind to THAT runtime instance (the device pointers
+    # it is handed come from torch's allocator).  Loaded before torch, libafr.so would pull in /opt/rocm's copy and the
+    # process would hold two HIP runtimes ("no ROCm-capable device is detected" at the first launch).
+    import torch  # noqa: F401
     lib = C.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported
