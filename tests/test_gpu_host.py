@@ -143,3 +143,16 @@ def test_training_reduces_the_loss_on_a_fixed_batch():
         eng.train_step(x, t)
         losses.append(eng.read_loss())
     assert losses[-1] < 0.6 * losses[0]
+
+
+def test_library_loaded_before_torch_still_shares_one_hip_runtime():
+    """A process that touches the C ABI before anything imported torch (as __graft_entry__.build() followed by smoke()
+    does) must still end up with ONE HIP runtime: _lib.load imports torch first."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; assert 'torch' not in sys.modules; "
+            "from ai_font_renderer_amd import _lib; assert _lib.lib().afr_version() == 1; "
+            "import __graft_entry__ as g; g.smoke()")
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "smoke ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
