@@ -243,6 +243,9 @@ __device__ __forceinline__ int fswz(int k) { return (k & 3) | (((k >> 3) & 1) <<
 typedef __attribute__((ext_vector_type(4))) int i32x4;
 __device__ __forceinline__ void dma16(i32x4 rsrc, unsigned lds_addr, unsigned voff) {
     unsigned keep;
+#ifdef AFR_GEMM_TIMING
+    lds_addr = __builtin_amdgcn_readfirstlane(lds_addr);   // the stamp branches cost the compiler its uniformity proof
+#endif
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(voff), "s"(lds_addr), "s"(rsrc) : "memory");
 }
@@ -304,6 +307,15 @@ __device__ __forceinline__ void nt_st4(float* q, float4 v) {
     __builtin_nontemporal_store(w, reinterpret_cast<f32x4*>(q));
 }
 #define ADST(ptr, val) nt_st4(ptr, val)
+// Kernel-development build (-DAFR_GEMM_TIMING, never the shipped library): thread 0 of every block leaves wall-clock
+// stamps (s_memrealtime, 10 ns ticks) at entry / first tile landed / K loop done / stores drained, plus its XCC and CU
+// ids, in a buffer of its own (tools/gemm_timeline.py); no output value depends on them.
+#ifdef AFR_GEMM_TIMING
+__device__ unsigned long long* g_gemm_stamps = nullptr;
+#define GSTAMP(i) do { if (stamps && tid == 0) stamps[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define GSTAMP(i) do { } while (0)
+#endif
 template <int ALAY, int BLAY, int WM>
 __global__ __launch_bounds__(128 * WM, 2) void gemm_bf16(GemmParams p) {
     constexpr int BM = 64 * WM, NW = 2 * WM, ASUB = WM / 2;
@@ -314,6 +326,16 @@ __global__ __launch_bounds__(128 * WM, 2) void gemm_bf16(GemmParams p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
+#ifdef AFR_GEMM_TIMING
+    unsigned long long* stamps = g_gemm_stamps;
+    GSTAMP(0);
+    if (stamps && tid == 0) {
+        unsigned xcc, hwid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        stamps[blockIdx.x * 8 + 4] = xcc; stamps[blockIdx.x * 8 + 5] = hwid;
+    }
+#endif
     int tm, tn, z;
     tile_of_block(p, BM, BN, tm, tn, z);
     const int m0 = tm * BM, n0 = tn * BN;
@@ -443,6 +465,7 @@ __global__ __launch_bounds__(128 * WM, 2) void gemm_bf16(GemmParams p) {
         else if (nt == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+        GSTAMP(1);
         bf16x8 a0[4], b0[4], a1[4], b1[4];
         if (nt > 0) { read_a(smem, 0, a0); read_b(smem, 0, b0); }
         int slot = 0;
@@ -468,6 +491,7 @@ __global__ __launch_bounds__(128 * WM, 2) void gemm_bf16(GemmParams p) {
         if (nt > 0) stage(0, 0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+        GSTAMP(1);
         int slot = 0;
         for (int t = 0; t < nt; ++t) {
             // tile t+1 streams into the other slot, which every wave finished reading before the last barrier
@@ -488,6 +512,7 @@ __global__ __launch_bounds__(128 * WM, 2) void gemm_bf16(GemmParams p) {
         }
     }
 
+    GSTAMP(2);
     if (ALAY == 1 && do_cs) {
         float* red = reinterpret_cast<float*>(smem);           // [16 row groups][BM]
         const int c = tid % CH, rg = tid / CH;
@@ -609,6 +634,11 @@ __global__ __launch_bounds__(128 * WM, 2) void gemm_bf16(GemmParams p) {
                 nt_st4(Cf + wi, make_float4(g[0], g[1], g[2], g[3]));
             }
         }
+#ifdef AFR_GEMM_TIMING
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        GSTAMP(3);
+#endif
         return;
     }
 #pragma unroll
@@ -663,10 +693,20 @@ __global__ __launch_bounds__(128 * WM, 2) void gemm_bf16(GemmParams p) {
         for (int w = 0; w < NW; ++w) bs += red[w];
         loss_block_finish(bs, p.mse_partial, p.mse_counter, p.mse_loss_accum, p.mse_inv_n, red + 16);
     }
+#ifdef AFR_GEMM_TIMING
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    GSTAMP(3);
+#endif
 }
 }  // namespace bf16k
 
 // ---------------------------------------------------------------------------------------- launch
+#ifdef AFR_GEMM_TIMING
+extern "C" int afr_dbg_gemm_stamps(void* devbuf) {
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(bf16k::g_gemm_stamps), &devbuf, sizeof(void*));
+}
+#endif
 // bf16: the 256x128 / 8-wave kernel when its grid fills most of the 256 CUs, else 128x128 / 4 waves
 static bool bf16_use_wide(const GemmParams& p) {
     // a fused-AdamW epilogue moves 26 B per output element and is the longer half of such a kernel; two 128x128 blocks

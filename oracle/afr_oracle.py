@@ -19,14 +19,30 @@ import torch
 
 
 # --------------------------------------------------------------------------- sheet model (R0)
-def _ident(t):
-    return t
-
-
-def bf16_round(t):
-    """Round-to-nearest-even to bfloat16 and back: lets the oracle mimic the throughput (bf16) mode, which
-    rounds the fc/GEMM operands (weights, activations, du, dz) to bf16 and accumulates in f32."""
+def bf16_round(t, site=None):
+    """Round-to-nearest-even to bfloat16 and back (a rounding hook that rounds at EVERY site)."""
     return t.to(torch.bfloat16).to(t.dtype)
+
+
+def _r(rnd, t, site):
+    return t if rnd is None else rnd(t, site)
+
+
+# The three products of a Linear layer (nn.Linear forward, model.py:148,152,183,196, and what autograd derives from it,
+# model.py:309), each with a rounding hook on every operand and on the result.  rnd=None -- the only mode the golden
+# fixtures pin -- is the reference's plain f32 arithmetic.  A checker of a mixed-precision implementation passes
+# rnd(tensor, site) -> tensor with site = "<layer>.<fwd|dw|dx>.<x|w|dy|y>"; WHICH sites an implementation rounds at is
+# that checker's knowledge (tests/util.py), never the oracle's.
+def linear_fwd(rnd, name, x, W, b):
+    return _r(rnd, _r(rnd, x, name + ".fwd.x") @ _r(rnd, W, name + ".fwd.w").t() + b, name + ".fwd.y")
+
+
+def linear_dw(rnd, name, dy, x):
+    return _r(rnd, dy, name + ".dw.dy").t() @ _r(rnd, x, name + ".dw.x")
+
+
+def linear_dx(rnd, name, dy, W):
+    return _r(rnd, _r(rnd, dy, name + ".dx.dy") @ _r(rnd, W, name + ".dx.w"), name + ".dx.y")
 
 
 def sheet_forward(P, x, cfg, masks=None, rnd=None, relu_mask=None):
@@ -39,7 +55,6 @@ def sheet_forward(P, x, cfg, masks=None, rnd=None, relu_mask=None):
     implementation under test and separately checks that they differ from its own only at |pre| ~ 0.
     Returns (y [B,h,w], cache) -- cache holds what sheet_backward needs.
     """
-    rnd = rnd or _ident
     B, Lin = x.shape
     L = min(Lin, cfg.max_length)                                  # model.py:163-164
     x = x[:, :L]
@@ -90,8 +105,7 @@ def sheet_forward(P, x, cfg, masks=None, rnd=None, relu_mask=None):
     z = fd.reshape(B, L * F)                                       # model.py:187
     if L < cfg.max_length:                                         # zero-pad branch, :190-193
         z = torch.cat([z, torch.zeros(B, (cfg.max_length - L) * F, dtype=dt)], dim=1)
-    z = rnd(z)
-    u = rnd(z @ rnd(P["fc_output.weight"]).t() + P["fc_output.bias"])   # model.py:196
+    u = linear_fwd(rnd, "fc_output", z, P["fc_output.weight"], P["fc_output.bias"])   # model.py:196
     y = u.clamp(0.0, 1.0).reshape(B, cfg.sheet_h, cfg.sheet_w)     # model.py:199-202
     cache = dict(x=x, L=L, e=e, qh=qh, kh=kh, vh=vh, A=A, Ad=Ad, o=o, rstd=rstd, xhat=xhat,
                  n=n, pre=pre, rmask=rmask, z=z, u=u, masks=masks)
@@ -104,16 +118,15 @@ def sheet_backward(P, cache, du, cfg, rnd=None):
     du: gradient w.r.t. the pre-clamp output u [B, pixels] (clamp mask already applied).
     Returns dict of the 12 gradients.
     """
-    rnd = rnd or _ident
     c = cache
     B = du.shape[0]
     L, E, H, F = c["L"], cfg.embed_dim, cfg.heads, cfg.fc_dim
     D = E // H
     masks = c["masks"]
     G = {}
-    G["fc_output.weight"] = du.t() @ c["z"]
+    G["fc_output.weight"] = linear_dw(rnd, "fc_output", du, c["z"])
     G["fc_output.bias"] = du.sum(0)
-    dz = rnd(du @ rnd(P["fc_output.weight"]))
+    dz = linear_dx(rnd, "fc_output", du, P["fc_output.weight"])
     dfd = dz[:, :L * F].reshape(B, L, F)
     df = dfd
     if masks is not None:
@@ -165,48 +178,40 @@ def sheet_backward(P, cache, du, cfg, rnd=None):
 def glyph_forward(P, x, font, cfg, rnd=None, relu_masks=None):
     """Per-glyph MLP built from the reference's layer idioms: Embedding gather (model.py:136,167)
     [+ font embedding], Linear+ReLU hidden layers (model.py:148,183), Linear + clamp output
-    (model.py:152-156,196-202).  Ancestor: learnings.md:3.  x,font: int64 [B]."""
-    rnd = rnd or _ident
+    (model.py:152-156,196-202).  Ancestor: learnings.md:3.  x,font: int64 [B].
+    Pinned by tests/golden/glyph_*.npz: the reference itself at max_length=1 (whose tail IS this network) and a
+    torch.nn-composed twin for the shapes the reference class cannot express (font table, deeper stacks)."""
     h = P["embedding.weight"][x]
     if cfg.n_fonts > 0:
         h = h + P["font_embedding.weight"][font]
-    h_exact = h
-    h = rnd(h)
     acts = [h]
     nh = len(cfg.hidden)
     pres, rmasks = [], []
     for i in range(nh):
-        if i == 0:      # the bf16 engine evaluates fc1 from the f32 tables and weights (no rounding before its ReLU)
-            pre = h_exact @ P["fc1.weight"].t() + P["fc1.bias"]
-        else:
-            pre = h @ rnd(P[f"fc{i + 1}.weight"]).t() + P[f"fc{i + 1}.bias"]
+        pre = linear_fwd(rnd, f"fc{i + 1}", h, P[f"fc{i + 1}.weight"], P[f"fc{i + 1}.bias"])
         pres.append(pre)
         rmasks.append((pre > 0) if relu_masks is None else relu_masks[i])
-        h = rnd(pre * rmasks[i].to(pre.dtype))
+        h = pre * rmasks[i].to(pre.dtype)
         acts.append(h)
-    u = rnd(h @ rnd(P["fc_output.weight"]).t() + P["fc_output.bias"])
+    u = linear_fwd(rnd, "fc_output", h, P["fc_output.weight"], P["fc_output.bias"])
     y = u.clamp(0.0, 1.0).reshape(-1, cfg.out_h, cfg.out_w)
     return y, dict(x=x, font=font, acts=acts, pres=pres, rmasks=rmasks, u=u)
 
 
 def glyph_backward(P, cache, du, cfg, rnd=None):
-    rnd = rnd or _ident
     G = {}
-    acts, pres = cache["acts"], cache["pres"]
+    acts = cache["acts"]
     nh = len(cfg.hidden)
-    G["fc_output.weight"] = du.t() @ acts[nh]
+    G["fc_output.weight"] = linear_dw(rnd, "fc_output", du, acts[nh])
     G["fc_output.bias"] = du.sum(0)
-    d = du @ rnd(P["fc_output.weight"])
+    d = linear_dx(rnd, "fc_output", du, P["fc_output.weight"])
     for i in reversed(range(nh)):
-        d = rnd(d * cache["rmasks"][i].to(d.dtype))
-        G[f"fc{i + 1}.weight"] = d.t() @ acts[i]
+        d = d * cache["rmasks"][i].to(d.dtype)                     # ReLU mask (threshold_backward)
+        G[f"fc{i + 1}.weight"] = linear_dw(rnd, f"fc{i + 1}", d, acts[i])
         G[f"fc{i + 1}.bias"] = d.sum(0)
-        # the bf16 engine folds fc1's input gradient into table-row sums in f32 (no rounded d0 exists there)
-        d = d @ (P["fc1.weight"] if i == 0 else rnd(P[f"fc{i + 1}.weight"]))
-    if nh == 0:
-        d = rnd(d)
+        d = linear_dx(rnd, f"fc{i + 1}", d, P[f"fc{i + 1}.weight"])
     dEmb = torch.zeros_like(P["embedding.weight"])
-    dEmb.index_add_(0, cache["x"], d)
+    dEmb.index_add_(0, cache["x"], d)                              # embedding_dense_backward
     G["embedding.weight"] = dEmb
     if cfg.n_fonts > 0:
         dF = torch.zeros_like(P["font_embedding.weight"])

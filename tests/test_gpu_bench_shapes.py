@@ -1,0 +1,238 @@
+"""GPU: the kernels bench.py times, at the shapes bench.py times them, against the CPU oracle / fp64.
+
+The bf16 launcher picks the 256x128 ring kernel only for grids that fill the chip (gemm.hip bf16_use_wide); the small
+shapes of test_gpu_ops / test_gpu_models never reach it.  Everything here does: the full C3 batch (8192 glyphs, bf16,
+fused loss, split-K weight gradients with fused bias gradients, grouped reduce, fused AdamW), C2 at its batch of 4096,
+afr_op_gemm in all four operand orientations with every epilogue, and the bit-exact embedding gather of the north star."""
+import itertools
+
+import numpy as np
+import pytest
+import torch
+
+from .util import GlyphConfig, engine_rounding, glyph_inputs, maxabs, oracle, rnd_du, synth, tparams
+
+pytestmark = pytest.mark.gpu
+
+
+def _engine(cfg, dtype="f32", max_batch=64, **kw):
+    from ai_font_renderer_amd.engine import Engine
+    eng = Engine(cfg, dtype=dtype, max_batch=max_batch, **kw)
+    eng.load_params(synth.make_params(cfg))
+    return eng
+
+
+def _rel(got, ref):
+    ref = np.asarray(ref, dtype=np.float64)
+    return maxabs(got, ref) / max(1e-7, float(np.abs(ref).max()))
+
+
+def _rand(tid, shape, bound=1.0):
+    return torch.from_numpy(synth.hash_uniform(tid, shape, bound))
+
+
+def _b16(t):
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+# ----------------------------------------------------------------------------- whole steps at the benchmarked batch
+def _oracle_step_with_engine_masks(cfg, dtype, eng, x, font, tu8):
+    """Oracle gradients for the engine's own ReLU / clamp masks (read back through afr_debug_copy), plus the check that
+    those masks differ from the oracle's own only where the oracle's pre-activation is within rounding of its threshold
+    (gradients are discontinuous there; see test_gpu_models.test_glyph_c3_shape_bf16_vs_oracle_and_f32_engine)."""
+    B = x.shape[0]
+    xt, ft = torch.from_numpy(x), torch.from_numpy(font)
+    rnd = engine_rounding(cfg, dtype)
+    eng.forward(xt, ft if cfg.n_fonts else None, want_output=False)
+    u_eng = eng.debug_read("u").view(B, -1).cpu()
+    rmasks = [eng.debug_read("act", i + 1).view(B, -1).cpu() > 0 for i in range(len(cfg.hidden))]
+    cmask = (u_eng >= 0) & (u_eng <= 1)
+    P = tparams(cfg)
+    _, own = oracle.glyph_forward(P, xt, ft, cfg, rnd=rnd)
+    eps = 2e-5 if dtype == "f32" else 2e-2
+    for i, m in enumerate(rmasks):
+        bad = m != (own["pres"][i] > 0)
+        assert bad.float().mean() < 1e-3 and (own["pres"][i][bad].abs() < eps).all(), (dtype, i)
+    badc = cmask != ((own["u"] >= 0) & (own["u"] <= 1))
+    assert badc.float().mean() < 1e-3 and (torch.minimum(own["u"][badc].abs(), (own["u"][badc] - 1).abs()) < eps).all()
+    _, cache = oracle.glyph_forward(P, xt, ft, cfg, rnd=rnd, relu_masks=rmasks)
+    assert maxabs(u_eng.numpy(), cache["u"].numpy()) < (2e-5 if dtype == "f32" else 3e-2)
+    tgt = torch.from_numpy(tu8.astype(np.float32) / 255.0)
+    lref, du = oracle.mse_loss_grad(cache["u"], tgt, clamp_mask=cmask)
+    return P, float(lref), oracle.glyph_backward(P, cache, rnd_du(rnd, du), cfg, rnd=rnd), u_eng
+
+
+@pytest.mark.parametrize("workload,dtype,tol", [("c3", "bf16", 3e-2), ("c2", "bf16", 3e-2), ("c3", "f32", 1e-4)])
+def test_benchmarked_batch_full_step_vs_oracle(workload, dtype, tol):
+    """BASELINE configs[2] (C3: 8192 glyphs, 1024-wide, font ids) and configs[1] (C2: 4096 glyphs, hidden 256) exactly as
+    bench.py runs them: afr_train_step with the loss fused into the last GEMM's epilogue, split-K weight-gradient GEMMs
+    with fused bias gradients, the grouped slab reduction -- every gradient against the oracle; then the fused
+    optimizer step against the oracle's AdamW on those gradients."""
+    from ai_font_renderer_amd.config import WORKLOADS
+    cfg, B = WORKLOADS[workload]["cfg"], WORKLOADS[workload]["batch"]
+    x, font, tu8 = glyph_inputs(cfg, B)
+    xt, ft, tt = torch.from_numpy(x), torch.from_numpy(font) if cfg.n_fonts else None, torch.from_numpy(tu8)
+    eng = _engine(cfg, dtype=dtype, max_batch=B)
+    P, lref, Gref, _ = _oracle_step_with_engine_masks(cfg, dtype, eng, x, font, tu8)
+    eng.read_loss()
+    eng.train_step(xt, tt, font=ft, do_step=False)              # the bench's kernels, gradients materialised
+    assert abs(eng.read_loss() - lref) < tol * lref
+    for k, g in eng.grads.items():
+        assert _rel(g.cpu().numpy(), Gref[k].numpy()) < tol, (workload, dtype, k)
+    # the step bench.py times (AdamW inside the slab reduction): t = 1, so every update is -lr * g / (|g| + eps) - decay.
+    # Compared with the oracle's AdamW on the ORACLE's gradients; entries whose gradient is ~0 may move the other way.
+    g_eng = {k: v.clone() for k, v in eng.grads.items()}
+    eng.train_step(xt, tt, font=ft, do_step=True)
+    eng.read_loss()
+    for k, v in eng.state_dict().items():
+        p1, _, _ = oracle.adamw_step(P[k], Gref[k], torch.zeros_like(P[k]), torch.zeros_like(P[k]), 1)
+        diff = (v.cpu() - p1).abs()
+        small = Gref[k].abs() < tol * Gref[k].abs().max()       # sign of the update undetermined within the tolerance
+        assert float(diff[~small].max() if (~small).any() else 0.0) < 2e-4, (workload, dtype, k)
+        assert float(diff.max()) <= 2.1e-3, k                   # never more than one full +-lr flip
+    # and, to rounding, what the stand-alone AdamW kernel makes of the ENGINE's own gradients
+    eng2 = _engine(cfg, dtype=dtype, max_batch=B)
+    for k in g_eng:
+        eng2.grads[k].copy_(g_eng[k])
+    eng2.adamw_step()
+    for k, v in eng.state_dict().items():
+        d = (v - eng2.params[k]).abs()
+        assert float(d.max()) <= 3e-6 * max(1.0, float(eng2.params[k].abs().max())), (workload, dtype, k)
+
+
+def test_c3_fused_loss_epilogue_equals_unfused_loss_kernel():
+    """The last forward GEMM of a C3 training step computes clamp / MSE / du in its epilogue (wide kernel, 256 blocks with
+    the ticketed loss reduction).  Same inputs through afr_forward + afr_loss_grad: du bit for bit, loss to f32 rounding;
+    and both against the oracle's mse_loss_grad on the engine's own u."""
+    from ai_font_renderer_amd.config import WORKLOADS
+    cfg, B = WORKLOADS["c3"]["cfg"], 8192
+    x, font, tu8 = glyph_inputs(cfg, B)
+    xt, ft, tt = torch.from_numpy(x), torch.from_numpy(font), torch.from_numpy(tu8)
+    eng = _engine(cfg, dtype="bf16", max_batch=B)
+    eng.forward(xt, ft, training=True, want_output=False)
+    u = eng.debug_read("u").view(B, -1).cpu()
+    eng.loss_grad(tt)
+    du_unfused, l_unfused = eng.debug_read("u").view(B, -1).cpu(), eng.read_loss()
+    eng.forward_loss(xt, tt, font=ft)
+    du_fused, l_fused = eng.debug_read("u").view(B, -1).cpu(), eng.read_loss()
+    assert torch.equal(du_fused, du_unfused)
+    assert abs(l_fused - l_unfused) <= 2e-6 * l_unfused
+    lref, du_ref = oracle.mse_loss_grad(u.double(), torch.from_numpy(tu8.astype(np.float64) / 255.0))
+    assert abs(l_fused - float(lref)) < 1e-5 * float(lref)
+    assert float((du_fused.double() - du_ref).abs().max()) <= 1e-2 * float(du_ref.abs().max())      # du is stored as bf16
+    assert float(du_fused[(u < 0) | (u > 1)].abs().max()) == 0.0
+
+
+# ----------------------------------------------------------------------------- the wide GEMM kernel through afr_op_gemm
+WIDE_SHAPES = [(8192, 1024, 1024), (4000, 2040, 520)]       # grids of 256 tiles of 256x128; the second ragged in M, N and K
+
+
+@pytest.mark.parametrize("ak,bk", list(itertools.product([False, True], repeat=2)))
+def test_wide_bf16_gemm_all_orientations_vs_fp64(ak, bk):
+    from .gpu_util import gemm
+    for si, (M, N, K) in enumerate(WIDE_SHAPES):
+        A, B = _b16(_rand(110 + si, (M, K))), _b16(_rand(120 + si, (N, K), 0.25))
+        ref = A.double() @ B.double().t()
+        scale = float(ref.abs().max())
+        got = gemm("bf16", A, B, ak, bk)
+        assert float((got.double() - ref).abs().max()) < 1e-5 * scale, (ak, bk, M, N, K)     # f32 accumulation of exact products
+        got = gemm("bf16", A, B, ak, bk, out_bf16=True)
+        assert float((got.double() - ref).abs().max()) < 1e-2 * scale, (ak, bk, M, N, K)
+
+
+def test_wide_bf16_gemm_epilogues_and_splitk():
+    from .gpu_util import gemm
+    M, N, K = 8192, 1024, 1024
+    A, B = _b16(_rand(131, (M, K))), _b16(_rand(132, (N, K), 0.2))
+    bias, aux = _rand(133, (N,)), _b16(_rand(134, (M, N)))
+    ref = A.double() @ B.double().t()
+    scale = float(ref.abs().max())
+    got = gemm("bf16", A, B, bias=bias, relu=True, out_bf16=True)                               # forward layer
+    assert float((got.double() - torch.relu(ref + bias.double())).abs().max()) < 1e-2 * scale
+    got = gemm("bf16", A, B, bias=bias, relu=True)
+    assert float((got.double() - torch.relu(ref + bias.double())).abs().max()) < 1e-5 * scale
+    got = gemm("bf16", A, B, b_kstrided=True, aux=aux, out_bf16=True)                           # input gradient with ReLU mask
+    assert float((got.double() - ref * (aux > 0)).abs().max()) < 1e-2 * scale
+    got = gemm("bf16", A, B, b_kstrided=True, aux=aux)
+    assert float((got.double() - ref * (aux > 0)).abs().max()) < 1e-5 * scale
+    # weight gradient: 1024 x 1024 output reduced over 8192, split-K 8 (256 blocks) and 3 (ragged split)
+    A2, B2 = _b16(_rand(141, (1024, 8192), 0.05)), _b16(_rand(142, (1024, 8192)))
+    ref2 = A2.double() @ B2.double().t()
+    for sk in (8, 3):
+        got = gemm("bf16", A2, B2, a_kstrided=True, b_kstrided=True, splitk=sk)
+        assert float((got.double() - ref2).abs().max()) < 2e-5 * float(ref2.abs().max()), sk
+
+
+# ----------------------------------------------------------------------------- bit-exact gather (north star)
+@pytest.mark.parametrize("cfgkw,B,xmax", [
+    (dict(hidden=(1024, 1024), out_h=32, out_w=32, n_fonts=2), 8192, None),       # C3: folded first layer (table gather)
+    (dict(hidden=(256,), out_h=16, out_w=16, n_fonts=0), 4096, None),            # C1/C2 net
+    (dict(hidden=(32,), out_h=4, out_w=4, n_fonts=2, vocab=600), 700, 600),      # too wide to fold: glyph_embed_kernel
+    (dict(hidden=(), out_h=4, out_w=6, n_fonts=2), 64, None),                    # no hidden layer: glyph_embed_kernel
+])
+def test_embedding_gather_is_bit_exact(cfgkw, B, xmax):
+    """nn.Embedding lookup (model.py:136,167): h0[b] == Emb[x_b] (+ Font[f_b]) bit for bit in f32 mode; the folded path's
+    one-hot columns are exactly {0,1} at exactly the two table rows a glyph uses."""
+    cfg = GlyphConfig(**cfgkw)
+    x, font, _ = glyph_inputs(cfg, B)
+    if xmax is not None:
+        x = (np.arange(B, dtype=np.int64) * 7) % xmax
+    eng = _engine(cfg, dtype="f32", max_batch=B)
+    eng.forward(torch.from_numpy(x), torch.from_numpy(font) if cfg.n_fonts else None, want_output=False)
+    E = cfg.embed_dim
+    h0 = eng.debug_read("act", 0).view(B, -1).cpu()
+    P = tparams(cfg)
+    want = P["embedding.weight"][torch.from_numpy(x)]
+    if cfg.n_fonts:
+        want = want + P["font_embedding.weight"][torch.from_numpy(font)]
+    assert torch.equal(h0[:, :E], want)
+    if h0.shape[1] > E:                                   # folded: [h0 | one-hot(x) | one-hot(vocab + f) | zero pad]
+        oh = torch.zeros(B, h0.shape[1] - E)
+        oh[torch.arange(B), torch.from_numpy(x)] = 1.0
+        if cfg.n_fonts:
+            oh[torch.arange(B), cfg.vocab + torch.from_numpy(font)] = 1.0
+        assert torch.equal(h0[:, E:], oh)
+    assert eng.error_flags() == 0
+    # bf16 mode stores the same sum rounded once to bf16
+    eng16 = _engine(cfg, dtype="bf16", max_batch=B)
+    eng16.forward(torch.from_numpy(x), torch.from_numpy(font) if cfg.n_fonts else None, want_output=False)
+    h16 = eng16.debug_read("act", 0).view(B, -1).cpu()
+    assert torch.equal(h16[:, :E], want.to(torch.bfloat16).float())
+
+
+def test_golden_glyph_fixtures_through_the_engine():
+    """The reference-pinned glyph fixtures (tests/golden/glyph_ref1.npz: the reference class at max_length=1;
+    glyph_twin.npz: torch.nn twin, 3 AdamW steps) replayed through the C ABI in f32 mode."""
+    from .util import load
+    from ai_font_renderer_amd.config import WORKLOADS
+    from ai_font_renderer_amd.engine import Engine
+    fx = load("glyph_ref1.npz")
+    h, w = fx["y"].shape[1:]
+    cfg = GlyphConfig(hidden=(64,), out_h=h, out_w=w, embed_dim=32, vocab=128, n_fonts=0)
+    eng = Engine(cfg, dtype="f32", max_batch=256)
+    P = {"embedding.weight": fx["table"]}
+    for k in ("fc1.weight", "fc1.bias", "fc_output.weight", "fc_output.bias"):
+        P[k] = fx["param/" + k]
+    eng.load_params(P)
+    x, t = torch.from_numpy(fx["x"]), torch.from_numpy(fx["target_u8"])
+    assert maxabs(eng.forward(x).cpu().numpy(), fx["y"]) < 2e-5
+    eng.train_step(x, t)
+    assert abs(eng.read_loss() - float(fx["loss"])) < 3e-6
+    for k in ("fc1.weight", "fc1.bias", "fc_output.weight", "fc_output.bias"):
+        assert maxabs(eng.params[k].cpu().numpy(), fx["step1/" + k]) < 2e-5, k
+    tw = load("glyph_twin.npz")
+    for tag, cfg, B in (("small", GlyphConfig(hidden=(48, 40), out_h=4, out_w=6, n_fonts=2), 300), ("c1", WORKLOADS["c1"]["cfg"], 95)):
+        x, font, tu8 = glyph_inputs(cfg, B)
+        xt, ft, tt = torch.from_numpy(x), torch.from_numpy(font) if cfg.n_fonts else None, torch.from_numpy(tu8)
+        eng = _engine(cfg, max_batch=B)
+        assert maxabs(eng.forward(xt, ft).cpu().numpy(), tw[f"{tag}/eval_y"]) < 2e-5
+        eng.train_step(xt, tt, font=ft, do_step=False)
+        eng.read_loss()
+        for k, g in eng.grads.items():
+            if f"{tag}/grad/{k}" in tw:
+                assert _rel(g.cpu().numpy(), tw[f"{tag}/grad/{k}"]) < 1e-4, (tag, k)
+        for i in range(3):
+            eng.train_step(xt, tt, font=ft)
+            assert abs(eng.read_loss() - float(tw[f"{tag}/losses"][i])) < 3e-6, (tag, i)
+        for k, v in eng.state_dict().items():
+            assert maxabs(v.cpu().numpy(), tw[f"{tag}/param3/{k}"]) < 2e-5, (tag, k)

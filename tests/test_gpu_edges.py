@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from .util import MINI, R0, maxabs, oracle, synth, tmasks, tparams
+from .util import MINI, R0, engine_rounding, maxabs, oracle, rnd_du, synth, tmasks, tparams
 
 pytestmark = pytest.mark.gpu
 
@@ -174,13 +174,13 @@ def _glyph_check(cfg, B, dtype="f32", tol=1e-4, ytol=2e-5, xmax=None):
         x = (np.arange(B, dtype=np.int64) * 7) % xmax
     eng = _engine(cfg, dtype=dtype, max_batch=max(B, 8))
     P = tparams(cfg)
-    rnd = oracle.bf16_round if dtype == "bf16" else None
+    rnd = engine_rounding(cfg, dtype)
     xt, ft = torch.from_numpy(x), torch.from_numpy(font)
     y = eng.forward(xt, ft if cfg.n_fonts else None).cpu().numpy()
     yref, cache = oracle.glyph_forward(P, xt, ft, cfg, rnd=rnd)
     assert maxabs(y, yref.numpy()) < ytol
     lref, du = oracle.mse_loss_grad(cache["u"], torch.from_numpy(tu8.astype(np.float32) / 255.0))
-    Gref = oracle.glyph_backward(P, cache, (rnd or (lambda t: t))(du), cfg, rnd=rnd)
+    Gref = oracle.glyph_backward(P, cache, rnd_du(rnd, du), cfg, rnd=rnd)
     eng.train_step(xt, torch.from_numpy(tu8), font=ft if cfg.n_fonts else None, do_step=False)
     assert abs(eng.read_loss() - float(lref)) < tol * float(lref)
     for k, g in eng.grads.items():

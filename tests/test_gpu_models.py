@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 import torch
 
-from .util import MINI, R0, GlyphConfig, glyph_inputs, load, maxabs, oracle, synth, tmasks, tparams
+from .util import MINI, R0, GlyphConfig, engine_rounding, glyph_inputs, load, maxabs, oracle, rnd_du, synth, tmasks, tparams
 
 pytestmark = pytest.mark.gpu
 
@@ -124,10 +124,10 @@ def test_sheet_train_step_vs_oracle_ragged_batch_dropout(dtype, tol):
     loss = eng.read_loss()
     P = tparams(cfg)
     masks = tmasks(synth.sheet_dropout_masks(cfg, B, 24, seed=5, step=11))
-    rnd = oracle.bf16_round if dtype == "bf16" else None     # the oracle rounds where the bf16 engine rounds
+    rnd = engine_rounding(cfg, dtype)                        # the checker rounds where the bf16 engine rounds
     _, cache = oracle.sheet_forward(P, torch.from_numpy(x), cfg, masks, rnd=rnd)
     lref, du = oracle.mse_loss_grad(cache["u"], torch.from_numpy(tu8.astype(np.float32) / 255.0))
-    Gref = oracle.sheet_backward(P, cache, (rnd or (lambda t: t))(du), cfg, rnd=rnd)
+    Gref = oracle.sheet_backward(P, cache, rnd_du(rnd, du), cfg, rnd=rnd)
     assert abs(loss - float(lref)) < tol * float(lref)
     for k, g in _grads(eng).items():
         assert _rel(g, Gref[k].numpy()) < tol, k
@@ -160,10 +160,10 @@ def test_out_of_range_code_sets_error_flag():
 # ----------------------------------------------------------------------------- glyph MLP family (BASELINE C1-C4)
 def _glyph_oracle_step(cfg, x, font, tu8, dtype="f32"):
     P = tparams(cfg)
-    rnd = oracle.bf16_round if dtype == "bf16" else None     # the oracle rounds where the bf16 engine rounds
+    rnd = engine_rounding(cfg, dtype)                        # the checker rounds where the bf16 engine rounds
     y, cache = oracle.glyph_forward(P, torch.from_numpy(x), torch.from_numpy(font), cfg, rnd=rnd)
     lref, du = oracle.mse_loss_grad(cache["u"], torch.from_numpy(tu8.astype(np.float32) / 255.0))
-    return y, float(lref), oracle.glyph_backward(P, cache, (rnd or (lambda t: t))(du), cfg, rnd=rnd)
+    return y, float(lref), oracle.glyph_backward(P, cache, rnd_du(rnd, du), cfg, rnd=rnd)
 
 
 @pytest.mark.parametrize("dtype,tol", [("f32", 1e-4), ("bf16", 3e-2)])
@@ -214,7 +214,7 @@ def test_glyph_c3_shape_bf16_vs_oracle_and_f32_engine():
     xt, ft = torch.from_numpy(x), torch.from_numpy(font)
     tgt = torch.from_numpy(tu8.astype(np.float32) / 255.0)
     for dtype, tol in (("f32", 1e-4), ("bf16", 3e-2)):
-        rnd = oracle.bf16_round if dtype == "bf16" else (lambda t: t)
+        rnd = engine_rounding(cfg, dtype)
         eng = _engine(cfg, dtype=dtype, max_batch=1024)
         eng.forward(xt, ft, want_output=False)
         u_eng = eng.debug_read("u").view(B, -1).cpu()
@@ -233,7 +233,7 @@ def test_glyph_c3_shape_bf16_vs_oracle_and_f32_engine():
         _, cache = oracle.glyph_forward(P, xt, ft, cfg, rnd=rnd, relu_masks=rmasks)
         assert maxabs(u_eng.numpy(), cache["u"].numpy()) < (2e-5 if dtype == "f32" else 3e-2)
         lref, du = oracle.mse_loss_grad(cache["u"], tgt, clamp_mask=cmask)
-        Gref = oracle.glyph_backward(P, cache, rnd(du), cfg, rnd=rnd)
+        Gref = oracle.glyph_backward(P, cache, rnd_du(rnd, du), cfg, rnd=rnd)
         assert abs(eng.read_loss() - float(lref)) < tol * float(lref), dtype
         for k, g in _grads(eng).items():
             assert _rel(g, Gref[k].numpy()) < tol, (dtype, k)

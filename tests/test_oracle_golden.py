@@ -131,6 +131,73 @@ def test_glyph_oracle_backward_matches_autograd_fp64():
         assert maxabs(G[k].numpy(), P[k].grad.numpy()) < 1e-10, k
 
 
+# ----------------------------------------------------------------------------- glyph MLP oracle: pinned, not self-checked
+def _glyph_ref1():
+    from .util import GlyphConfig
+    fx = load("glyph_ref1.npz")
+    h, w = fx["y"].shape[1:]
+    cfg = GlyphConfig(hidden=(64,), out_h=h, out_w=w, embed_dim=32, vocab=128, n_fonts=0)
+    P = {"embedding.weight": _t(fx["table"])}
+    for k in ("fc1.weight", "fc1.bias", "fc_output.weight", "fc_output.bias"):
+        P[k] = _t(fx["param/" + k])
+    return fx, cfg, P
+
+
+def test_glyph_oracle_matches_reference_class_at_max_length_1():
+    """the reference's AttentionFontRenderer(max_length=1) ends in exactly the glyph network
+    (fc1+ReLU -> fc_output -> clamp, model.py:148,152-156,183,196-202) fed by a per-code vector; the fixture holds that
+    table and the REFERENCE's outputs, loss, autograd gradients and tensors after one step of its AdamW."""
+    fx, cfg, P = _glyph_ref1()
+    x = _t(fx["x"])
+    tgt = _t(fx["target_u8"].astype(np.float32) / 255.0)
+    y, cache = oracle.glyph_forward(P, x, None, cfg)
+    assert maxabs(y.numpy(), fx["y"]) < 2e-6
+    loss, du = oracle.mse_loss_grad(cache["u"], tgt)
+    assert abs(float(loss) - float(fx["loss"])) < 1e-6
+    G = oracle.glyph_backward(P, cache, du, cfg)
+    for k in ("fc1.weight", "fc1.bias", "fc_output.weight", "fc_output.bias"):
+        ref = fx["grad/" + k]
+        assert maxabs(G[k].numpy(), ref) <= 2e-5 * float(np.abs(ref).max()), k
+        p1, _, _ = oracle.adamw_step(P[k], G[k], torch.zeros_like(P[k]), torch.zeros_like(P[k]), 1)
+        assert maxabs(p1.numpy(), fx["step1/" + k]) < 2e-6, k
+
+
+def _twin_case(tag):
+    from .util import GlyphConfig, glyph_inputs
+    from ai_font_renderer_amd.config import WORKLOADS
+    cfg, B = (GlyphConfig(hidden=(48, 40), out_h=4, out_w=6, n_fonts=2), 300) if tag == "small" else (WORKLOADS["c1"]["cfg"], 95)
+    x, font, tu8 = glyph_inputs(cfg, B)
+    return cfg, _t(x), _t(font), _t(tu8.astype(np.float32) / 255.0)
+
+
+def test_glyph_oracle_matches_torch_nn_twin_fonts_and_two_hidden_layers():
+    """Shapes the reference class cannot express (font table, deeper stack, BASELINE C1): goldens from a torch.nn-composed
+    twin that make_golden.py checks against the imported reference on the overlapping parameterisation."""
+    fx = load("glyph_twin.npz")
+    for tag in ("small", "c1"):
+        cfg, x, font, tgt = _twin_case(tag)
+        P = tparams(cfg)
+        y, cache = oracle.glyph_forward(P, x, font, cfg)
+        assert maxabs(y.numpy(), fx[f"{tag}/eval_y"]) < 2e-6, tag
+        loss, du = oracle.mse_loss_grad(cache["u"], tgt)
+        assert abs(float(loss) - float(fx[f"{tag}/losses"][0])) < 1e-6
+        G = oracle.glyph_backward(P, cache, du, cfg)
+        n = 0
+        for k in P:
+            if f"{tag}/grad/{k}" in fx:
+                ref = fx[f"{tag}/grad/{k}"]
+                assert maxabs(G[k].numpy(), ref) <= 2e-5 * float(np.abs(ref).max()), (tag, k)
+                n += 1
+        assert n >= 5
+        M = {k: torch.zeros_like(v) for k, v in P.items()}
+        V = {k: torch.zeros_like(v) for k, v in P.items()}
+        for t in (1, 2, 3):
+            loss, _, P, M, V = oracle.train_step(P, M, V, t, x, tgt, cfg, font=font)
+            assert abs(float(loss) - float(fx[f"{tag}/losses"][t - 1])) < 2e-6, (tag, t)
+        for k in P:
+            assert maxabs(P[k].numpy(), fx[f"{tag}/param3/{k}"]) < 5e-6, (tag, k)
+
+
 def test_text_generator_matches_survey_strings():
     """generate_font.ts:164-199 restated; first strings for seeds 42..44."""
     assert synth.lcg_text(42) == "P JAL WZ MQWPCDYYX EOGYVE MBANVV"

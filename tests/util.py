@@ -42,3 +42,33 @@ def glyph_inputs(cfg, B, seed=0):
     font = ((i // 95) % max(cfg.n_fonts, 1)).astype(np.int64)
     t = synth.hash_u8(910 + seed, (B, cfg.out_h, cfg.out_w))
     return x, font, t
+
+
+# ---------------------------------------------------------------- rounding points of the bf16 (throughput) engine
+def engine_rounding(cfg, dtype):
+    """Rounding hook for the oracle (oracle.linear_fwd/dw/dx sites) that mimics where the HIP engine's bf16 mode
+    rounds to bfloat16.  This is knowledge about the IMPLEMENTATION UNDER TEST and lives with its tests; the oracle
+    itself stays the reference's plain f32 arithmetic (rnd=None).  Returns None for the f32 (parity) mode.
+
+    bf16 mode: GEMM operands are bf16 (weights from the bf16 shadow, stored activations, du, dz/dx), accumulation and
+    epilogues are f32, stored results are bf16.  Exception -- the glyph model's FOLDED first layer (csrc/elementwise.hip
+    glyph_table/l1 kernels, used when 0 < hidden layers and K0 = E + vocab + fonts <= 512 and E <= 128): fc1 is evaluated
+    from the f32 tables and f32 W1 (only its result h1 is rounded), and its input gradient is folded into f32 table-row
+    sums (no rounded d0, f32 W1); the stored h0' that feeds dW1 IS bf16."""
+    if dtype != "bf16":
+        return None
+    b16 = oracle.bf16_round
+    folded = False
+    if getattr(cfg, "kind", "") == "glyph" and len(cfg.hidden) > 0:
+        k0 = cfg.embed_dim + (cfg.vocab + cfg.n_fonts + 7) // 8 * 8
+        folded = k0 <= 512 and cfg.embed_dim <= 128
+    unrounded = {"fc1.fwd.x", "fc1.fwd.w", "fc1.dx.w", "fc1.dx.y"} if folded else set()
+
+    def rnd(t, site=None):
+        return t if site in unrounded else b16(t)
+    return rnd
+
+
+def rnd_du(rnd, du):
+    """du leaves the loss epilogue as a stored bf16 tensor in bf16 mode."""
+    return du if rnd is None else oracle.bf16_round(du)
