@@ -59,6 +59,7 @@ SIGNATURES = {
     "afr_debug_copy": (_i32, [_vp, _i32, _vp, _sz, C.POINTER(_sz), _vp]),
     "afr_op_gemm": (_i32, [_i32, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "afr_op_reduce": (_i32, [_vp, _vp, _i32, _i64, _i64, _f32, _i32, _vp]),
+    "afr_op_reduce_group": (_i32, [_i32, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_i32), C.POINTER(_i64), C.POINTER(_i64), _vp]),
     "afr_op_adamw": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _i64, _f32, _vp]),
     "afr_op_mse_grad": (_i32, [_i32, _vp, _vp, _i32, _vp, _i64, _i64, _i64, _vp, _vp, _vp]),
     "afr_op_f32_to_bf16": (_i32, [_vp, _vp, _i64, _vp]),

@@ -26,6 +26,23 @@ static int fail(int code, const char* fmt, ...) {
         if (e_ != hipSuccess) return fail(AFR_EHIP, "%s: %s", #expr, hipGetErrorString(e_)); \
     } while (0)
 
+// Every entry point that enqueues work makes the device that owns the caller's buffers current for the duration of the
+// call (and restores the previous one): kernels are launched on the caller's stream, which belongs to that device, so a
+// process whose current device is another GPU (LOCAL_RANK != 0 without a set_device) still launches where the data lives.
+static int device_of(const void* ptr) {
+    hipPointerAttribute_t a;
+    if (!ptr || hipPointerGetAttributes(&a, ptr) != hipSuccess) { (void)hipGetLastError(); return -1; }
+    return a.device;
+}
+struct DevGuard {
+    int prev = -1; bool switched = false;
+    explicit DevGuard(int dev) {
+        if (dev < 0 || hipGetDevice(&prev) != hipSuccess || prev == dev) return;
+        switched = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DevGuard() { if (switched) (void)hipSetDevice(prev); }
+};
+
 extern "C" int afr_version(void) { return AFR_VERSION; }
 extern "C" const char* afr_last_error(void) { return g_err; }
 
@@ -48,6 +65,7 @@ struct afr_plan {
     float *P = nullptr, *G = nullptr, *M = nullptr, *V = nullptr;
     char* ws = nullptr;
     size_t ws_bytes = 0, ws_need = 0;
+    int device = -1;               // the GPU that owns the bound buffers (afr_bind)
     // workspace offsets (bytes)
     size_t o_shadow = 0, o_err = 0, o_loss = 0, o_u = 0, o_z = 0, o_dz = 0, o_slab_e = 0, o_save = 0;
     std::vector<size_t> o_act;     // glyph: activations h0..h_nh
@@ -70,7 +88,7 @@ struct afr_plan {
     int next_stage = 0;
     // profiling
     int prof_mode = 0;      // 0 off, 1 every launch, 2 only prof_only
-    int prof_only = -1;
+    std::string prof_only_sym;   // mode 2: the kernel symbol to keep timing
     double prof_overhead_ms = -1.0;   // event-bracket overhead, measured on first use (prof_calibrate)
     std::vector<ProfRec> prof;
     std::vector<std::string> prof_tags;
@@ -97,6 +115,7 @@ static int64_t off_of(const afr_plan* p, const char* name) {
     return -1;
 }
 
+static_assert(AFR_RT_MAXSEG >= 2 * (AFR_MAX_HIDDEN + 1) + 4, "a backward pass of the deepest glyph net must fit one grouped reduce");
 #ifndef AFR_SPLITK_TARGET
 #define AFR_SPLITK_TARGET 512
 #endif
@@ -223,6 +242,18 @@ extern "C" int afr_plan_create(const afr_config* c, afr_plan** out) {
         delete p;
         return fail(AFR_EINVAL, "unknown model kind %d", c->kind);
     }
+    if (c->dtype == AFR_BF16) {
+        // every bf16 GEMM operand (activations [max_batch][width], weight shadows) is addressed with 32-bit byte offsets
+        long long widest = Pix;
+        for (const auto& l : p->layers) { if (l.N > widest) widest = l.N; if (l.K > widest) widest = l.K; }
+        if ((long long)c->max_batch * widest * 2 >= (1ll << 31)) {
+            const long long lim = ((1ll << 31) - 1) / (widest * 2);
+            delete p;
+            return fail(AFR_EUNSUPPORTED, "max_batch %d too large for bf16 mode: an activation operand would reach 2 GiB (limit %lld rows of %lld)", c->max_batch, lim, widest);
+        }
+        for (const auto& l : p->layers)
+            if ((long long)l.N * l.K * 2 >= (1ll << 31)) { delete p; return fail(AFR_EUNSUPPORTED, "a %d x %d weight is 2 GiB or more in bf16", l.N, l.K); }
+    }
     p->ws_need = off;
     *out = p;
     return AFR_OK;
@@ -256,6 +287,12 @@ extern "C" int afr_bind(afr_plan* p, float* params, float* grads, float* m, floa
     if (ws_bytes < p->ws_need) return fail(AFR_EINVAL, "workspace too small: %zu < %zu", ws_bytes, p->ws_need);
     if (((uintptr_t)params | (uintptr_t)grads | (uintptr_t)m | (uintptr_t)v | (uintptr_t)ws) & 255)
         return fail(AFR_EINVAL, "buffers must be 256-byte aligned");
+    const int dev = device_of(params);
+    for (const void* q : {(const void*)grads, (const void*)m, (const void*)v, (const void*)ws}) {
+        const int d = device_of(q);
+        if (q && d >= 0 && dev >= 0 && d != dev) return fail(AFR_EINVAL, "buffers live on different devices (%d and %d)", dev, d);
+    }
+    p->device = dev;
     p->P = params; p->G = grads; p->M = m; p->V = v;
     p->ws = (char*)ws; p->ws_bytes = ws_bytes;
     p->have_du = false;
@@ -292,13 +329,17 @@ static void prof_calibrate(afr_plan* p, hipStream_t s) {
     }
     if (best < 1e8f) p->prof_overhead_ms = 0.5 * best;
 }
+// "gemm_bf16<1,1,4>[1024x1024x8192]" -> "gemm_bf16<1,1,4>": the symbol rocprofv3 reports; launches of one symbol with
+// different shapes are recorded apart (per-shape table) and summed per symbol when the dominant KERNEL is picked
+static std::string symbol_of(const std::string& tag) { return tag.substr(0, tag.find('[')); }
 struct ProfScope {
     afr_plan* p; hipStream_t s; ProfRec r; bool on;
     ProfScope(afr_plan* p_, hipStream_t s_, const char* tag, double flops, double bytes) : p(p_), s(s_), on(p_->prof_mode != 0) {
         if (!on) return;
         if (p->prof_overhead_ms < 0.0) prof_calibrate(p, s);
         r.tag = tag_id(p, tag);
-        if (p->prof_mode == 2 && r.tag != p->prof_only) { on = false; return; } r.flops = flops; r.bytes = bytes; r.a = ev_get(p); r.b = ev_get(p);
+        if (p->prof_mode == 2 && symbol_of(p->prof_tags[r.tag]) != p->prof_only_sym) { on = false; return; }
+        r.flops = flops; r.bytes = bytes; r.a = ev_get(p); r.b = ev_get(p);
         (void)hipEventRecord(r.a, s);
     }
     ~ProfScope() { if (on) { (void)hipEventRecord(r.b, s); p->prof.push_back(r); } }
@@ -316,18 +357,34 @@ static int prof_totals(afr_plan* p, std::vector<double>& tot, std::vector<double
     }
     return AFR_OK;
 }
+// per-symbol sums of a per-tag table
+struct SymAgg { std::string sym; double tot = 0, fl = 0, by = 0; int64_t cnt = 0; };
+static std::vector<SymAgg> prof_by_symbol(afr_plan* p, const std::vector<double>& tot, const std::vector<double>& fl,
+                                          const std::vector<double>& by, const std::vector<int64_t>& cnt) {
+    std::vector<SymAgg> out;
+    for (size_t i = 0; i < tot.size(); ++i) {
+        if (!cnt[i]) continue;
+        const std::string sy = symbol_of(p->prof_tags[i]);
+        size_t k = 0;
+        while (k < out.size() && out[k].sym != sy) ++k;
+        if (k == out.size()) { out.emplace_back(); out[k].sym = sy; }
+        out[k].tot += tot[i]; out[k].fl += fl[i]; out[k].by += by[i]; out[k].cnt += cnt[i];
+    }
+    return out;
+}
 extern "C" int afr_profile_dominant(afr_plan* p, int mode) {
     if (!p) return fail(AFR_EINVAL, "null plan");
-    if (mode == 2) {     // keep timing only the kernel that dominated the launches recorded so far
-        if (p->prof.empty() && p->prof_only < 0)
+    if (mode == 2) {     // keep timing only the kernel (symbol) that dominated the launches recorded so far
+        if (p->prof.empty() && p->prof_only_sym.empty())
             return fail(AFR_ESTATE, "mode 2 needs a mode-1 recording to pick the dominant kernel from");
         if (!p->prof.empty() && p->prof_mode == 1) {
             std::vector<double> tot, fl, by; std::vector<int64_t> cnt;
             int rc = prof_totals(p, tot, fl, by, cnt);
             if (rc) return rc;
+            const std::vector<SymAgg> ag = prof_by_symbol(p, tot, fl, by, cnt);
             size_t best = 0;
-            for (size_t i = 1; i < tot.size(); ++i) if (tot[i] > tot[best]) best = i;
-            p->prof_only = (int)best;
+            for (size_t i = 1; i < ag.size(); ++i) if (ag[i].tot > ag[best].tot) best = i;
+            p->prof_only_sym = ag[best].sym;
         }
     }
     for (auto& r : p->prof) { p->ev_pool.push_back(r.a); p->ev_pool.push_back(r.b); }
@@ -342,13 +399,14 @@ extern "C" int afr_profile_read(afr_plan* p, char* name, int cap, double* avg_ms
     std::vector<double> tot, fl, by; std::vector<int64_t> cnt;
     int rc = prof_totals(p, tot, fl, by, cnt);
     if (rc) return rc;
+    const std::vector<SymAgg> ag = prof_by_symbol(p, tot, fl, by, cnt);
     size_t best = 0;
-    for (size_t i = 1; i < tot.size(); ++i) if (tot[i] > tot[best]) best = i;
-    if (name && cap > 0) { strncpy(name, p->prof_tags[best].c_str(), cap - 1); name[cap - 1] = 0; }
-    if (avg_ms) *avg_ms = tot[best] / (double)cnt[best];
-    if (launches) *launches = cnt[best];
-    if (flops) *flops = fl[best] / (double)cnt[best];
-    if (bytes) *bytes = by[best] / (double)cnt[best];
+    for (size_t i = 1; i < ag.size(); ++i) if (ag[i].tot > ag[best].tot) best = i;
+    if (name && cap > 0) { strncpy(name, ag[best].sym.c_str(), cap - 1); name[cap - 1] = 0; }
+    if (avg_ms) *avg_ms = ag[best].tot / (double)ag[best].cnt;
+    if (launches) *launches = ag[best].cnt;
+    if (flops) *flops = ag[best].fl / (double)ag[best].cnt;
+    if (bytes) *bytes = ag[best].by / (double)ag[best].cnt;
     return AFR_OK;
 }
 
@@ -378,6 +436,11 @@ static int run_gemm(afr_plan* p, hipStream_t s, int flags, const void* A, const 
                     const void* aux, int M, int N, int K, int lda, int ldb, int ldc, int ldaux, int splitk,
                     long long slab_stride, float* colsum = nullptr, long long colsum_stride = 0, const FusedLoss* fl = nullptr,
                     const FusedAdam* fa = nullptr) {
+    if (p->cfg.dtype == AFR_BF16) {
+        const bool ak = flags & AFR_GEMM_A_KSTRIDED, bk = flags & AFR_GEMM_B_KSTRIDED;
+        const long long ea = (long long)(ak ? K : M) * lda * 2, ebb = (long long)(bk ? K : N) * ldb * 2;
+        if (ea >= (1ll << 31) || ebb >= (1ll << 31)) return fail(AFR_EUNSUPPORTED, "bf16 GEMM operand of 2 GiB or more (%lld / %lld bytes)", ea, ebb);
+    }
     GemmParams g;
     if (fa) {
         g.ad_p = fa->p; g.ad_m = fa->m; g.ad_v = fa->v; g.ad_shadow = fa->shadow;
@@ -394,10 +457,12 @@ static int run_gemm(afr_plan* p, hipStream_t s, int flags, const void* A, const 
     g.flags = flags; g.splitk = splitk; g.slab_stride = slab_stride;
     const double eb = p->cfg.dtype == AFR_BF16 ? 2.0 : 4.0;
     const double ob = (flags & AFR_GEMM_OUT_BF16) ? 2.0 : 4.0;
-    // algorithmic bytes: operands once + output once; with the fused optimizer the output is p,m,v read + p,m,v(,shadow) written
-    const double out_bytes = fa ? (double)M * N * (24.0 + (fa->shadow ? 2.0 : 0.0)) : ob * (double)M * N * splitk;
-    ProfScope ps(p, s, afr_gemm_kernel_name(p->cfg.dtype, g), 2.0 * M * (double)N * K,
-                 eb * ((double)M * K + (double)N * K) + out_bytes);
+    // algorithmic bytes: operands once + the product once (split-K partial slabs are an implementation choice, not
+    // algorithmic output); with the fused optimizer the output is p,m,v read + p,m,v(,shadow) written
+    const double out_bytes = fa ? (double)M * N * (24.0 + (fa->shadow ? 2.0 : 0.0)) : (splitk > 1 ? 4.0 : ob) * (double)M * N;
+    char tag[96];
+    snprintf(tag, sizeof tag, "%s[%dx%dx%d]", afr_gemm_kernel_name(p->cfg.dtype, g), M, N, K);
+    ProfScope ps(p, s, tag, 2.0 * M * (double)N * K, eb * ((double)M * K + (double)N * K) + out_bytes);
     HIPCHK(afr_launch_gemm(p->cfg.dtype, g, s));
     return AFR_OK;
 }
@@ -428,6 +493,7 @@ static int run_reduce_group(afr_plan* p, hipStream_t s, const RTable& rt) {
 
 extern "C" int afr_sync_params(afr_plan* p, void* stream) {
     if (!p || !p->P) return fail(AFR_ESTATE, "plan has no bound parameters");
+    DevGuard dg(p->device);
     if (p->cfg.dtype != AFR_BF16) return AFR_OK;
     HIPCHK(afr_launch_f32_to_bf16(p->P, (bf16_t*)(p->ws + p->o_shadow), p->total, (hipStream_t)stream));
     return AFR_OK;
@@ -461,6 +527,7 @@ static SheetParams sheet_params(const afr_plan* p) {
 static int forward_impl(afr_plan* p, const int64_t* x, const int64_t* font, int B, int L, float* y, int training,
                         uint64_t step, void* stream, const FusedLoss* fl) {
     if (!p || !p->P) return fail(AFR_ESTATE, "plan has no bound parameters");
+    DevGuard dg(p->device);
     if (!x) return fail(AFR_EINVAL, "x is null");
     if (B <= 0 || B > p->cfg.max_batch) return fail(AFR_EINVAL, "batch %d outside 1..max_batch=%d", B, p->cfg.max_batch);
     hipStream_t s = (hipStream_t)stream;
@@ -531,6 +598,7 @@ extern "C" int afr_forward(afr_plan* p, const int64_t* x, const int64_t* font, i
 extern "C" int afr_loss_grad(afr_plan* p, const void* target, int tdtype, int B, int64_t mean_elems, float* loss_accum,
                              void* stream) {
     if (!p || !p->P) return fail(AFR_ESTATE, "plan has no bound parameters");
+    DevGuard dg(p->device);
     if (!target || !loss_accum) return fail(AFR_EINVAL, "target and loss_accum are required");
     if (B != p->last_B) return fail(AFR_ESTATE, "loss_grad batch %d does not match the last forward (%d)", B, p->last_B);
     if (tdtype != AFR_TARGET_U8 && tdtype != AFR_TARGET_F32) return fail(AFR_EINVAL, "bad target dtype");
@@ -548,6 +616,7 @@ extern "C" int afr_loss_grad(afr_plan* p, const void* target, int tdtype, int B,
 
 extern "C" int afr_set_output_grad(afr_plan* p, const float* dy, int B, void* stream) {
     if (!p || !p->P) return fail(AFR_ESTATE, "plan has no bound parameters");
+    DevGuard dg(p->device);
     if (!dy) return fail(AFR_EINVAL, "dy is null");
     if (B != p->last_B) return fail(AFR_ESTATE, "batch %d does not match the last forward (%d)", B, p->last_B);
     HIPCHK(afr_launch_clamp_bwd(p->cfg.dtype, p->ws + p->o_u, dy, (long long)B * p->cfg.out_h * p->cfg.out_w, (hipStream_t)stream));
@@ -674,6 +743,7 @@ extern "C" int afr_backward_stages(const afr_plan* p) {
 
 extern "C" int afr_backward_stage(afr_plan* p, int stage, int64_t* grad_offset, int64_t* grad_elems, void* stream) {
     if (!p || !p->P || !p->G) return fail(AFR_ESTATE, "plan has no bound parameter/gradient buffers");
+    DevGuard dg(p->device);
     const int n = afr_backward_stages(p);
     if (stage < 0 || stage >= n) return fail(AFR_EINVAL, "stage %d outside 0..%d", stage, n - 1);
     if (stage == 0 && !p->have_du) return fail(AFR_ESTATE, "backward needs a forward + loss first");
@@ -687,6 +757,7 @@ extern "C" int afr_backward_stage(afr_plan* p, int stage, int64_t* grad_offset, 
 
 extern "C" int afr_backward(afr_plan* p, void* stream) {
     if (!p || !p->P || !p->G) return fail(AFR_ESTATE, "plan has no bound parameter/gradient buffers");
+    DevGuard dg(p->device);
     if (!p->have_du) return fail(AFR_ESTATE, "afr_backward needs afr_forward + afr_loss_grad first");
     const int n = afr_backward_stages(p);
     RTable rt;
@@ -706,6 +777,7 @@ extern "C" int afr_backward(afr_plan* p, void* stream) {
 extern "C" int afr_adamw_step(afr_plan* p, float lr, float b1, float b2, float eps, float wd, int64_t t, float gscale,
                               void* stream) {
     if (!p || !p->P || !p->G || !p->M || !p->V) return fail(AFR_ESTATE, "AdamW needs params, grads and both moments bound");
+    DevGuard dg(p->device);
     if (t < 1) return fail(AFR_EINVAL, "t starts at 1");
     hipStream_t s = (hipStream_t)stream;
     const float bc1 = (float)(1.0 - std::pow((double)b1, (double)t));
@@ -805,6 +877,8 @@ extern "C" int afr_train_step(afr_plan* p, const int64_t* x, const int64_t* font
     if (!target || !loss_accum) return fail(AFR_EINVAL, "target and loss_accum are required");
     if (tdtype != AFR_TARGET_U8 && tdtype != AFR_TARGET_F32) return fail(AFR_EINVAL, "bad target dtype");
     if (mean_elems <= 0) return fail(AFR_EINVAL, "mean_elems must be positive");
+    if (!p || !p->P) return fail(AFR_ESTATE, "plan has no bound parameters");
+    DevGuard dg(p->device);
     // the loss and its gradient are computed in the epilogue of the last forward GEMM: u never touches HBM
     FusedLoss fl{target, tdtype, mean_elems, loss_accum};
     if ((rc = forward_impl(p, x, font, B, L, nullptr, 1, step, stream, &fl))) return rc;
@@ -830,6 +904,7 @@ extern "C" int afr_train_step(afr_plan* p, const int64_t* x, const int64_t* font
 
 extern "C" int afr_error_flags(afr_plan* p, void* stream, uint32_t* out) {
     if (!p || !p->ws || !out) return fail(AFR_EINVAL, "plan must be bound and out non-null");
+    DevGuard dg(p->device);
     hipStream_t s = (hipStream_t)stream;
     HIPCHK(hipMemcpyAsync(out, p->ws + p->o_err, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
@@ -839,6 +914,7 @@ extern "C" int afr_error_flags(afr_plan* p, void* stream, uint32_t* out) {
 
 extern "C" int afr_debug_copy(afr_plan* p, int which, void* dst, size_t cap, size_t* bytes_out, void* stream) {
     if (!p || !p->ws || !dst) return fail(AFR_EINVAL, "plan must be bound and dst non-null");
+    DevGuard dg(p->device);
     if (p->last_B <= 0) return fail(AFR_ESTATE, "no forward has run yet");
     const afr_config& c = p->cfg;
     const size_t B = (size_t)p->last_B, ab = (size_t)p->act_bytes;
@@ -868,6 +944,12 @@ extern "C" int afr_op_gemm(int dtype, int flags, const void* A, const void* B, v
         return fail(AFR_EUNSUPPORTED, "contiguous extents and leading dimensions must be multiples of %d", v);
     if (splitk > 1 && (flags & (AFR_GEMM_BIAS | AFR_GEMM_RELU | AFR_GEMM_RELU_MASK | AFR_GEMM_OUT_BF16)))
         return fail(AFR_EINVAL, "split-K output is plain f32 partial slabs");
+    if (dtype == AFR_BF16) {      // the LDS-DMA path addresses an operand with 32-bit byte offsets: 2 GiB per operand
+        const long long ea = (long long)(ak ? K : M) * lda * 2, ebb = (long long)(bk ? K : N) * ldb * 2;
+        if (ea >= (1ll << 31) || ebb >= (1ll << 31))
+            return fail(AFR_EUNSUPPORTED, "a bf16 GEMM operand must be smaller than 2 GiB (A %lld bytes, B %lld bytes)", ea, ebb);
+    }
+    DevGuard dg(device_of(C));
     GemmParams g;
     g.A = A; g.B = B; g.C = C; g.bias = bias; g.aux = aux; g.M = M; g.N = N; g.K = K;
     g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldaux = ldaux; g.flags = flags; g.splitk = splitk;
@@ -878,12 +960,28 @@ extern "C" int afr_op_gemm(int dtype, int flags, const void* A, const void* B, v
 extern "C" int afr_op_reduce(float* dst, const float* slabs, int nslabs, int64_t stride, int64_t n, float scale, int acc,
                              void* stream) {
     if (!dst || !slabs || nslabs < 1) return fail(AFR_EINVAL, "bad reduce arguments");
+    DevGuard dg(device_of(dst));
     HIPCHK(afr_launch_reduce(dst, slabs, nslabs, stride, n, scale, acc, (hipStream_t)stream));
+    return AFR_OK;
+}
+extern "C" int afr_op_reduce_group(int nseg, float* const* dst, const float* const* slabs, const int* nslabs, const int64_t* stride,
+                                   const int64_t* n, void* stream) {
+    if (nseg < 0 || (nseg > 0 && (!dst || !slabs || !nslabs || !stride || !n))) return fail(AFR_EINVAL, "bad grouped-reduce arguments");
+    if (nseg > AFR_RT_MAXSEG) return fail(AFR_EINVAL, "a grouped reduce takes at most %d segments (got %d)", AFR_RT_MAXSEG, nseg);
+    RTable rt;
+    for (int i = 0; i < nseg; ++i) {
+        if (!dst[i] || !slabs[i] || nslabs[i] < 1 || n[i] < 0 || (n[i] & 3)) return fail(AFR_EINVAL, "segment %d: null pointer, no slabs or length not a multiple of 4", i);
+        afr_rtable_add(rt, dst[i], slabs[i], nslabs[i], stride[i], n[i]);
+    }
+    if (nseg == 0) return AFR_OK;
+    DevGuard dg(device_of(dst[0]));
+    HIPCHK(afr_launch_reduce_group(rt, (hipStream_t)stream));
     return AFR_OK;
 }
 extern "C" int afr_op_adamw(float* p, const float* g, float* m, float* v, void* shadow, int64_t n, float lr, float b1,
                             float b2, float eps, float wd, int64_t t, float gscale, void* stream) {
     if (!p || !g || !m || !v || t < 1) return fail(AFR_EINVAL, "bad AdamW arguments");
+    DevGuard dg(device_of(p));
     const float bc1 = (float)(1.0 - std::pow((double)b1, (double)t));
     const float bc2 = (float)(1.0 - std::pow((double)b2, (double)t));
     HIPCHK(afr_launch_adamw(p, g, m, v, (bf16_t*)shadow, n, lr, b1, b2, eps, wd, bc1, bc2, gscale, (hipStream_t)stream));
@@ -892,11 +990,13 @@ extern "C" int afr_op_adamw(float* p, const float* g, float* m, float* v, void* 
 extern "C" int afr_op_mse_grad(int act_dtype, const void* u, const void* target, int tdtype, void* du, int64_t rows,
                                int64_t cols, int64_t mean_elems, float* loss_accum, float* scratch, void* stream) {
     if (!u || !target || !du || !loss_accum || !scratch) return fail(AFR_EINVAL, "null argument");
+    DevGuard dg(device_of(du));
     HIPCHK(afr_launch_mse_grad(act_dtype, u, target, tdtype, du, rows, cols, mean_elems, loss_accum, scratch,
                                (hipStream_t)stream));
     return AFR_OK;
 }
 extern "C" int afr_op_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream) {
+    DevGuard dg(device_of(dst));
     HIPCHK(afr_launch_f32_to_bf16(src, (bf16_t*)dst, n, (hipStream_t)stream));
     return AFR_OK;
 }

@@ -130,13 +130,16 @@ hipError_t afr_launch_reduce(float* dst, const float* slabs, int nslabs, long lo
                              float scale, int accumulate, hipStream_t s);
 // grouped reduction: every gradient tensor that was produced as partial slabs, in ONE launch
 struct RSeg { float* dst; const float* src; long long stride; long long n4; int nslabs; int blk0; int nblk; int deep; };
+// every gradient tensor of the deepest glyph net (AFR_MAX_HIDDEN + 1 Linears: weight + bias each) plus the folded first
+// layer's extra segments (compact dW1, embedding and font partials) fits; afr_api.hip static_asserts it
+constexpr int AFR_RT_MAXSEG = 24;
 struct RTable {
-    int nseg; int nblocks;
+    int nseg = 0; int nblocks = 0; int overflow = 0;
     // optional fused optimizer: the summed gradient is not stored; AdamW is applied to p/m/v at the same flat offset
     // (offset of seg.dst from `gbase`)
-    int adam; float ad_decay, ad_b1, ad_b2, ad_eps, ad_step, ad_rsqrt_bc2;
+    int adam = 0; float ad_decay, ad_b1, ad_b2, ad_eps, ad_step, ad_rsqrt_bc2;
     const float* gbase; float* P; float* M; float* V; bf16_t* shadow;
-    RSeg seg[24];
+    RSeg seg[AFR_RT_MAXSEG];
 };
 void afr_rtable_add(RTable& t, float* dst, const float* src, int nslabs, long long stride, long long n);
 hipError_t afr_launch_reduce_group(const RTable& t, hipStream_t s);

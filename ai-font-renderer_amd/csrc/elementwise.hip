@@ -132,7 +132,8 @@ __global__ __launch_bounds__(256) void reduce_group_kernel(RTable t) {
     }
 }
 void afr_rtable_add(RTable& t, float* dst, const float* src, int nslabs, long long stride, long long n) {
-    if (n <= 0 || t.nseg >= 24) return;
+    if (n <= 0) return;
+    if (t.nseg >= AFR_RT_MAXSEG) { t.overflow = 1; return; }     // the launch refuses an overflowed table: never a silent drop
     RSeg& sg = t.seg[t.nseg];
     sg.dst = dst; sg.src = src; sg.stride = stride; sg.n4 = n / 4; sg.nslabs = nslabs; sg.blk0 = t.nblocks;
     sg.deep = nslabs >= 32;
@@ -144,6 +145,7 @@ void afr_rtable_add(RTable& t, float* dst, const float* src, int nslabs, long lo
     t.nseg++;
 }
 hipError_t afr_launch_reduce_group(const RTable& t, hipStream_t s) {
+    if (t.overflow) return hipErrorInvalidValue;
     if (t.nseg == 0) return hipSuccess;
     hipLaunchKernelGGL(reduce_group_kernel, dim3(t.nblocks), dim3(256), 0, s, t);
     return hipGetLastError();
@@ -468,9 +470,12 @@ hipError_t afr_launch_glyph_l1_fwd(int act_dtype, const float* emb, const float*
     const int K0 = afr_glyph_k0(E, vocab, n_fonts);
     const int rows = vocab + n_fonts;
     const size_t tlds = (size_t)(256 * (E + 1) + GT_ROWS * E) * sizeof(float);      // 35 KB at E = 32, 136 KB at the E = 128 limit
-    if (tlds > 48 * 1024) {
+    static size_t tlds_set[16];                      // largest dynamic-LDS opt-in made so far, per device
+    int dev = 0;
+    if (tlds > 48 * 1024 && hipGetDevice(&dev) == hipSuccess && (dev < 0 || dev >= 16 || tlds_set[dev] < tlds)) {
         hipError_t e = hipFuncSetAttribute((const void*)glyph_table_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tlds);
         if (e != hipSuccess) return e;
+        if (dev >= 0 && dev < 16) tlds_set[dev] = tlds;
     }
     hipLaunchKernelGGL(glyph_table_kernel, dim3((rows + GT_ROWS - 1) / GT_ROWS, (N1 + 255) / 256), dim3(256), tlds, s, emb, font_emb,
                        W1, vocab, rows, E, N1, table);

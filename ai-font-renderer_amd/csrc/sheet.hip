@@ -327,7 +327,11 @@ __global__ __launch_bounds__(NT) void sheet_bwd_kernel(SheetDims dm, SheetParams
     for (int k = 0; k < KPOS; ++k) aPos[k] = 0.f;
     const float scale = 0.35355339059327373f;
     const size_t Kz = (size_t)dm.Lmax * F;
-    float* Sblk = slabs + (size_t)blockIdx.x * so.total;       // this block's partial slab (zeroed by the host memset)
+    float* Sblk = slabs + (size_t)blockIdx.x * so.total;       // this block's partial slab
+    // The block zeroes its own slab (55 KB, L2): the embedding rows are accumulated into it string by string, rows of dP
+    // beyond a short input and the padding between tensors must read as zero in the grouped reduce.  (This used to be a
+    // 14 MB host-side memset launch in front of every backward.)  The first accumulation is many barriers away.
+    for (int i = tid0; i < so.total / 4; i += NT) reinterpret_cast<float4*>(Sblk)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     const bool saved = dr.save != nullptr;
 #ifdef AFR_SHEET_TIMING
     long long tacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast = wall_clock64();
@@ -577,17 +581,31 @@ static inline int al4h(int n) { return (n + 3) & ~3; }
 size_t afr_sheet_fwd_lds_bytes(const SheetDims& d) { return d.L <= LMAX ? (size_t)FWD_FLOATS * sizeof(float) : (size_t)-1; }
 size_t afr_sheet_bwd_lds_bytes(const SheetDims& d) { return d.L <= LMAX ? (size_t)BWD_FLOATS * sizeof(float) : (size_t)-1; }
 
+// the opt-in to > 64 KiB of dynamic LDS is a property of the (device, kernel) pair: set once, not per launch
+template <typename K>
+static hipError_t lds_optin_once(K kernel, size_t lds, bool (&done)[16]) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 0 || dev >= 16 || !done[dev]) {
+        if ((e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
+        if (dev >= 0 && dev < 16) done[dev] = true;
+    }
+    return hipSuccess;
+}
+
 hipError_t afr_launch_sheet_fwd(int act_dtype, const SheetDims& d, const SheetParams& P, const SheetDrop& dr, const int64_t* x,
                                 int ldx, int B, void* z, float ln_eps, uint32_t* err_flag, hipStream_t s) {
     if (B <= 0) return hipSuccess;
     const size_t lds = afr_sheet_fwd_lds_bytes(d);
     dim3 g(afr_sheet_blocks(B)), blk(NT);
     hipError_t e;
+    static bool opt16[16], opt32[16];
     if (act_dtype == AFR_BF16) {
-        if ((e = hipFuncSetAttribute((const void*)sheet_fwd_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
+        if ((e = lds_optin_once(sheet_fwd_kernel<bf16_t>, lds, opt16)) != hipSuccess) return e;
         hipLaunchKernelGGL(sheet_fwd_kernel<bf16_t>, g, blk, lds, s, d, P, dr, x, ldx, B, (bf16_t*)z, ln_eps, err_flag);
     } else {
-        if ((e = hipFuncSetAttribute((const void*)sheet_fwd_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
+        if ((e = lds_optin_once(sheet_fwd_kernel<float>, lds, opt32)) != hipSuccess) return e;
         hipLaunchKernelGGL(sheet_fwd_kernel<float>, g, blk, lds, s, d, P, dr, x, ldx, B, (float*)z, ln_eps, err_flag);
     }
     return hipGetLastError();
@@ -598,14 +616,15 @@ hipError_t afr_launch_sheet_bwd(int act_dtype, const SheetDims& d, const SheetPa
     if (B <= 0) return hipSuccess;
     const size_t lds = afr_sheet_bwd_lds_bytes(d);
     const int nb = afr_sheet_blocks(B);
-    hipError_t e = hipMemsetAsync(slabs, 0, (size_t)nb * so.total * sizeof(float), s);
-    if (e != hipSuccess) return e;
+    if (so.total & 3) return hipErrorInvalidValue;             // the kernel zeroes its slab 16 bytes at a time
+    hipError_t e;
+    static bool opt16[16], opt32[16];
     dim3 g(nb), blk(NT);
     if (act_dtype == AFR_BF16) {
-        if ((e = hipFuncSetAttribute((const void*)sheet_bwd_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
+        if ((e = lds_optin_once(sheet_bwd_kernel<bf16_t>, lds, opt16)) != hipSuccess) return e;
         hipLaunchKernelGGL(sheet_bwd_kernel<bf16_t>, g, blk, lds, s, d, P, dr, x, ldx, B, (const bf16_t*)dz, ln_eps, slabs, so);
     } else {
-        if ((e = hipFuncSetAttribute((const void*)sheet_bwd_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
+        if ((e = lds_optin_once(sheet_bwd_kernel<float>, lds, opt32)) != hipSuccess) return e;
         hipLaunchKernelGGL(sheet_bwd_kernel<float>, g, blk, lds, s, d, P, dr, x, ldx, B, (const float*)dz, ln_eps, slabs, so);
     }
     return hipGetLastError();

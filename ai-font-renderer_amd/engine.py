@@ -19,8 +19,10 @@ def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 
 
-def _stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+def _stream(device=None):
+    """The caller's current stream ON `device` (torch.cuda.current_stream() alone is the stream of the process's current
+    device, which is GPU 0 unless somebody called set_device)."""
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
 def make_afr_config(cfg, dtype, max_batch, seed=42, rank=0):
@@ -83,6 +85,12 @@ class Engine:
         self.t = 0            # AdamW step counter (model.py:310)
         self._keep = None     # keeps the last inputs alive until backward has consumed them
 
+    def _call(self, fn, *args):
+        """One libafr call that enqueues work: on THIS engine's device and on the caller's current stream of that device
+        (the engine may live on cuda:k while the process's current device is another GPU)."""
+        with torch.cuda.device(self.device):
+            _lib.check(fn(*args, _stream(self.device)))
+
     def _make_plan(self, max_batch):
         if self._plan:
             self.lib.afr_plan_destroy(self._plan)
@@ -126,7 +134,7 @@ class Engine:
         self.sync_params()
 
     def sync_params(self):
-        _lib.check(self.lib.afr_sync_params(self._plan, _stream()))
+        self._call(self.lib.afr_sync_params, self._plan)
 
     def state_dict(self):
         return {nm: self.params[nm].detach().clone() for nm, _, _, _ in self.layout}
@@ -154,7 +162,7 @@ class Engine:
             x = x.reshape(-1)
             B, L = x.shape[0], 1
         y = torch.empty(B, self.pixels, dtype=torch.float32, device=self.device) if want_output else None
-        _lib.check(self.lib.afr_forward(self._plan, _ptr(x), _ptr(font), B, L, _ptr(y), int(bool(training)), int(step), _stream()))
+        self._call(self.lib.afr_forward, self._plan, _ptr(x), _ptr(font), B, L, _ptr(y), int(bool(training)), int(step))
         self._keep = (x, font)
         if y is None:
             return None
@@ -170,17 +178,17 @@ class Engine:
         t, td = self._target(target)
         B = t.shape[0]
         me = int(mean_elems) if mean_elems is not None else B * self.pixels
-        _lib.check(self.lib.afr_loss_grad(self._plan, _ptr(t), td, B, me, _ptr(self.loss_accum), _stream()))
+        self._call(self.lib.afr_loss_grad, self._plan, _ptr(t), td, B, me, _ptr(self.loss_accum))
         self._keep_t = t
 
     def set_output_grad(self, dy):
         """dy = d(loss)/d(clamped output) from a caller-side loss (autograd); float32 [B, pixels]."""
         dy = dy.to(self.device, dtype=torch.float32).contiguous()
-        _lib.check(self.lib.afr_set_output_grad(self._plan, _ptr(dy), dy.shape[0], _stream()))
+        self._call(self.lib.afr_set_output_grad, self._plan, _ptr(dy), dy.shape[0])
         self._keep_t = dy
 
     def backward(self):
-        _lib.check(self.lib.afr_backward(self._plan, _stream()))
+        self._call(self.lib.afr_backward, self._plan)
 
     @property
     def backward_stages(self):
@@ -189,7 +197,7 @@ class Engine:
     def backward_stage(self, stage):
         """Run one backward stage; returns the view of flat_grads that is final after it."""
         off, n = C.c_int64(), C.c_int64()
-        _lib.check(self.lib.afr_backward_stage(self._plan, int(stage), C.byref(off), C.byref(n), _stream()))
+        self._call(self.lib.afr_backward_stage, self._plan, int(stage), C.byref(off), C.byref(n))
         return self.flat_grads[off.value:off.value + n.value]
 
     def forward_loss(self, x, target, font=None, step=None, mean_elems=None):
@@ -204,12 +212,12 @@ class Engine:
             B, L = x.shape[0], 1
         me = int(mean_elems) if mean_elems is not None else B * self.pixels
         st = int(step if step is not None else self.t + 1)
-        _lib.check(self.lib.afr_forward_loss(self._plan, _ptr(x), _ptr(font), _ptr(t), td, B, L, me, _ptr(self.loss_accum), st, _stream()))
+        self._call(self.lib.afr_forward_loss, self._plan, _ptr(x), _ptr(font), _ptr(t), td, B, L, me, _ptr(self.loss_accum), st)
         self._keep, self._keep_t = (x, font), t
 
     def adamw_step(self, lr=1e-3, betas=(0.9, 0.99), eps=1e-8, weight_decay=5e-4, grad_scale=1.0):
         self.t += 1
-        _lib.check(self.lib.afr_adamw_step(self._plan, lr, betas[0], betas[1], eps, weight_decay, self.t, grad_scale, _stream()))
+        self._call(self.lib.afr_adamw_step, self._plan, lr, betas[0], betas[1], eps, weight_decay, self.t, grad_scale)
 
     def train_step(self, x, target, font=None, step=None, lr=1e-3, betas=(0.9, 0.99), eps=1e-8, weight_decay=5e-4,
                    mean_elems=None, do_step=True):
@@ -226,8 +234,8 @@ class Engine:
         if do_step:
             self.t += 1
         st = int(step if step is not None else self.t)
-        _lib.check(self.lib.afr_train_step(self._plan, _ptr(x), _ptr(font), _ptr(t), td, B, L, me, _ptr(self.loss_accum), st,
-                                           int(bool(do_step)), lr, betas[0], betas[1], eps, weight_decay, max(self.t, 1), _stream()))
+        self._call(self.lib.afr_train_step, self._plan, _ptr(x), _ptr(font), _ptr(t), td, B, L, me, _ptr(self.loss_accum), st,
+                                           int(bool(do_step)), lr, betas[0], betas[1], eps, weight_decay, max(self.t, 1))
         self._keep = (x, font)
         self._keep_t = t
 
@@ -239,7 +247,8 @@ class Engine:
 
     def error_flags(self):
         out = C.c_uint32(0)
-        _lib.check(self.lib.afr_error_flags(self._plan, _stream(), C.byref(out)))
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.afr_error_flags(self._plan, _stream(self.device), C.byref(out)))
         return out.value
 
     def debug_read(self, which, index=0):
@@ -250,8 +259,8 @@ class Engine:
         cap = self.max_batch * max(self.pixels, getattr(self.cfg, "flat_dim", 0), *(getattr(self.cfg, "hidden", (0,))), self.cfg.embed_dim) * es
         buf = torch.empty(cap, dtype=torch.uint8, device=self.device)
         n = C.c_size_t()
-        _lib.check(self.lib.afr_debug_copy(self._plan, code, _ptr(buf), cap, C.byref(n), _stream()))
-        torch.cuda.synchronize()
+        self._call(self.lib.afr_debug_copy, self._plan, code, _ptr(buf), cap, C.byref(n))
+        torch.cuda.synchronize(self.device)
         return buf[:n.value].view(dt).float()
 
     # ---------------------------------------------------------------- measurement

@@ -57,8 +57,20 @@ torch.manual_seed(SEED)
 _LOCAL_RANK = int(os.environ.get("LOCAL_RANK", "0"))
 if torch.cuda.is_available():
     device = torch.device("cuda", _LOCAL_RANK)
+    torch.cuda.set_device(device)              # one process per GPU: torch ops AND libafr launches of this process go to it
 else:                                          # importable for inspection; constructing a model will raise
     device = torch.device("cpu")
+
+
+def _init_distributed():
+    """torchrun --nproc-per-node N model.py --train: one rank per GPU, gradients all-reduced over RCCL (parallel.py).
+    Without WORLD_SIZE > 1 in the environment this is a no-op (single GPU, as the reference)."""
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1 and dist.is_available() and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29512")
+        dist.init_process_group("nccl", device_id=device)      # "nccl" is RCCL on ROCm
 
 # the reference's 15 evaluation inputs (model.py:111-127): rendered every 5 epochs and at the end
 test_strings = [
@@ -160,8 +172,23 @@ class AttentionFontRenderer(nn.Module):
         self.fc_output = _Bag(weight=P["fc_output.weight"], bias=P["fc_output.bias"])
         self.strict_indices = True
         self._steps = 0
+        self._seen_versions = None
         if init:
             self.engine.load_params(_reference_style_init(self.config))
+
+    def _param_versions(self):
+        return tuple(p._version for p in self.parameters())
+
+    def _refresh_shadow_if_params_changed(self):
+        """bf16 mode: the GEMMs read a bf16 shadow of the f32 masters that only libafr's own AdamW keeps current.  A stock
+        torch optimizer (or any in-place edit of a Parameter) bumps the tensor's version counter; when the counters moved
+        since the last forward the shadow is re-derived first, so the next forward sees the new weights."""
+        if self.engine.dtype not in ("bf16", "bfloat16"):
+            return
+        v = self._param_versions()
+        if v != self._seen_versions:
+            self.engine.sync_params()
+            self._seen_versions = v
 
     def _next_step(self):
         self._steps += 1
@@ -170,6 +197,7 @@ class AttentionFontRenderer(nn.Module):
     def forward(self, x):
         if x.dim() != 2:
             raise ValueError(f"expected [batch, seq_len] codes, got shape {tuple(x.shape)}")
+        self._refresh_shadow_if_params_changed()
         if torch.is_grad_enabled() and self.training:
             y = _EngineForward.apply(self.positional_encoding, self, x)
         else:
@@ -355,6 +383,7 @@ def train_string_renderer():
 def main(argv=None):
     """The reference's __main__ block (model.py:425-454)."""
     argv = sys.argv if argv is None else argv
+    _init_distributed()
     print(f"Using HIP device: {torch.cuda.get_device_name(device) if torch.cuda.is_available() else 'none'}")
     print(f"Device: {device}")
     os.makedirs(OUTPUT_DIR, exist_ok=True)

@@ -2,6 +2,7 @@
 """bench.py -- glyphs/sec of one full training step (forward + MSE + backward + AdamW) of the hot path.
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3|c2|c1|r0] [--dtype bf16|f32]
+         (run directly with N > 1 it starts its own N rank processes before touching a GPU)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
          bench.py --gpus N --steps K --warmup W          (one rank per GPU, RCCL)
 
@@ -101,12 +102,98 @@ def cpu_baseline(name, cfg, B, budget_s=12.0):
 def pmc_traffic(workload, kernel):
     """HBM bytes per launch of `kernel` from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE run
     separately on this same command; FETCH doubled per the gfx950 rule; tools/pmc_summary.py), or None."""
-    path = os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")
-    try:
-        d = json.load(open(path))[workload][kernel]
-        return d["read_bytes"] + d["write_bytes"]
-    except Exception:
-        return None
+    for rnd in ("r02", "r01"):
+        path = os.path.join(ROOT, "profiles", rnd, "pmc_traffic.json")
+        try:
+            d = json.load(open(path))[workload][kernel]
+            return d["read_bytes"] + d["write_bytes"], f"profiles/{rnd}/pmc_traffic.json"
+        except Exception:
+            continue
+    return None, None
+
+
+def step_flops(cfg, B):
+    """Algorithmic FLOPs of one training step, SURVEY.md 8(d): 3 x the forward GEMM FLOPs (forward, dX, dW)."""
+    if isinstance(cfg, SheetConfig):
+        L, E, F, H = cfg.max_length, cfg.embed_dim, cfg.fc_dim, cfg.heads
+        fwd = 2.0 * L * (E * 3 * E + E * E + E * F) + 2.0 * 2 * L * L * E + 2.0 * (L * F) * cfg.pixels      # 248.27 MFLOP at R0
+        return 3.0 * fwd * B
+    return 3.0 * B * sum(2.0 * n * k for n, k in cfg.layer_dims())
+
+
+def widest_linear(cfg):
+    """(N, K) of the widest Linear: fc_output for the sheet model, the hidden x hidden layers of the glyph nets."""
+    if isinstance(cfg, SheetConfig):
+        return cfg.pixels, cfg.max_length * cfg.fc_dim
+    return max(cfg.layer_dims(), key=lambda nk: nk[0] * nk[1])
+
+
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` run directly: start N rank processes (one per GPU, RCCL) BEFORE this process touches a
+    GPU, let rank 0's JSON line through on stdout, and exit with the launcher's status."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.run(cmd, env=env).returncode
+
+
+def measure(name, dtype, B, K, W, rank, world, dist, with_roofline=True):
+    """W warm-up steps, then exactly K timed steps between fences.  Returns (engine, elapsed_s, dominant, table, loss)."""
+    from ai_font_renderer_amd.engine import Engine
+    from ai_font_renderer_amd.parallel import DataParallelStepper
+    cfg = WORKLOADS[name]["cfg"]
+    eng = Engine(cfg, dtype=dtype, max_batch=B, rank=rank)
+    eng.load_params(synth.make_params(cfg))                           # same formula-generated weights on every rank
+    x, font, tgt = make_inputs(name, cfg, B, rank)
+    x, tgt = x.cuda(), tgt.cuda()
+    font = font.cuda() if font is not None else None
+    force_dp = os.environ.get("AFR_BENCH_FORCE_DP") == "1"
+    stepper = DataParallelStepper(eng, dist, 2 if (force_dp and world == 1) else world)
+    mean_elems = world * B * cfg.pixels
+
+    def run(n):
+        for _ in range(n):
+            stepper.step(x, tgt, font, mean_elems)
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    table, dom = [], None
+    if with_roofline:
+        # warm-up; its last steps run with every launch timed, to find the dominant kernel and the per-shape table
+        run(max(W - 3, 1))
+        torch.cuda.synchronize()
+        eng.profile(1)
+        run(min(W, 3) if W > 0 else 1)
+        torch.cuda.synchronize()
+        table = eng.profile_table()
+        eng.profile(2)                                                # timed region: events around the dominant kernel only
+    else:
+        run(max(W, 1))
+    fence()
+    t0 = time.perf_counter()
+    run(K)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if with_roofline:
+        dom = eng.profile_read()
+        eng.profile(0)
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    loss = eng.read_loss() / max(K + W, 1)
+    if eng.error_flags():
+        raise SystemExit("device error flag set (embedding index out of range)")
+    return eng, elapsed, dom, table, loss
 
 
 def main():
@@ -118,16 +205,16 @@ def main():
     ap.add_argument("--dtype", default=None, choices=["bf16", "f32"])
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch override (changes the workload: for experiments only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the parity-mode (f32) and R0 side records")
     ap.add_argument("--table", action="store_true", help="also print the per-kernel time table to stderr")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))                # nothing above this line touches a GPU
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N>1 must be launched with python -m torch.distributed.run --nproc-per-node N")
-        args.gpus = world
+    args.gpus = world
     name = args.workload
     cfg = WORKLOADS[name]["cfg"]
     B = args.batch or WORKLOADS[name]["batch"]
@@ -147,82 +234,82 @@ def main():
         else:
             dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
 
-    from ai_font_renderer_amd.engine import Engine
-    from ai_font_renderer_amd.parallel import DataParallelStepper
-    eng = Engine(cfg, dtype=dtype, max_batch=B, rank=rank)
-    eng.load_params(synth.make_params(cfg))                           # same formula-generated weights on every rank
-    x, font, tgt = make_inputs(name, cfg, B, rank)
-    x, tgt = x.cuda(), tgt.cuda()
-    font = font.cuda() if font is not None else None
-    stepper = DataParallelStepper(eng, dist, 2 if (force_dp and world == 1) else world)
-    mean_elems = world * B * cfg.pixels
-
-    def run(n):
-        for _ in range(n):
-            stepper.step(x, tgt, font, mean_elems)
-
-    def fence():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    # warm-up; its last steps run with every launch timed, to find the dominant kernel
-    run(max(W - 3, 1))
-    torch.cuda.synchronize()
-    eng.profile(1)
-    run(min(W, 3) if W > 0 else 1)
-    torch.cuda.synchronize()
-    table = eng.profile_table()
-    eng.profile(2)                                                    # timed region: events around the dominant kernel only
-    fence()
-    t0 = time.perf_counter()
-    run(K)
-    fence()
-    elapsed = time.perf_counter() - t0
-    dom = eng.profile_read()
-    eng.profile(0)
-    if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-    loss = eng.read_loss() / max(K + W, 1)
-    if eng.error_flags():
-        raise SystemExit("device error flag set (embedding index out of range)")
+    eng, elapsed, dom, table, loss = measure(name, dtype, B, K, W, rank, world, dist)
 
     if rank == 0:
         value = world * B * K / elapsed
-        # price the dominant kernel against both roofs with its ALGORITHMIC work; the binding one is the larger fraction
+        ms_step = elapsed / K * 1e3
+        # The dominant kernel against the roof SURVEY.md 8(d) names for it: the MFMA peak of its operand type for the dense
+        # products (C3, R0 in f32), HBM for the streaming kernels and for R0's bf16 weight-gradient GEMM with the fused
+        # optimizer (26 B of p/m/v traffic per output element; 8(d): "bf16 mode: HBM until B >~ 2700/GPU").
         secs = dom["avg_ms"] * 1e-3
-        f32_kernel = dom["kernel"].startswith(("sheet_", "gemm_f32"))
+        kern = dom["kernel"]
+        f32_kernel = kern.startswith(("sheet_", "gemm_f32"))
         peak_fl = PEAK["f32"] if f32_kernel else PEAK[dtype]           # f32 VALU peak == f32 MFMA peak (157.3 TF)
         fl = dom["algo_flops"] / secs / 1e12
         by = dom["algo_bytes"] / secs / 1e9
-        if dom["algo_flops"] > 0 and fl / peak_fl >= by / HBM_PEAK_GBS:
-            roof = {"bound": "mfma" if dom["kernel"].startswith("gemm") else "valu", "kernel": dom["kernel"], "achieved": fl,
-                    "peak": peak_fl, "unit": "TFLOP/s", "frac": fl / peak_fl, "traffic": None, "avg_launch_ms": dom["avg_ms"],
-                    "launches": dom["launches"], "algo_flops_per_launch": dom["algo_flops"], "algo_bytes_per_launch": dom["algo_bytes"]}
+        hbm_bound = dom["algo_flops"] <= 0 or (name == "r0" and dtype == "bf16" and kern.startswith("gemm_bf16<1,1"))
+        if hbm_bound:
+            roof = {"bound": "hbm", "kernel": kern, "achieved": by, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": by / HBM_PEAK_GBS}
         else:
-            roof = {"bound": "hbm", "kernel": dom["kernel"], "achieved": by, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": by / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": dom["avg_ms"], "launches": dom["launches"],
-                    "algo_bytes_per_launch": dom["algo_bytes"], "algo_flops_per_launch": dom["algo_flops"]}
-        roof["traffic"] = pmc_traffic(name, dom["kernel"]) if (dtype == DEFAULT_DTYPE[name] and not args.batch) else None
-        roof["traffic_unit"] = "bytes/launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r01/pmc_traffic.json)"
+            roof = {"bound": "mfma" if kern.startswith("gemm") else "valu", "kernel": kern, "achieved": fl, "peak": peak_fl,
+                    "unit": "TFLOP/s", "frac": fl / peak_fl}
+        tr, src = pmc_traffic(name, kern) if (dtype == DEFAULT_DTYPE[name] and not args.batch) else (None, None)
+        roof.update({"traffic": tr, "traffic_unit": f"bytes/launch (PMC FETCH_SIZE x2 + WRITE_SIZE, {src})" if src else None,
+                     "avg_launch_ms": dom["avg_ms"], "launches": dom["launches"], "algo_flops_per_launch": dom["algo_flops"],
+                     "algo_bytes_per_launch": dom["algo_bytes"], "mfma_frac": fl / peak_fl if dom["algo_flops"] > 0 else None,
+                     "hbm_frac": by / HBM_PEAK_GBS})
+        # whole step against the MFMA peak, and the three products of the widest Linear (per-shape rows of the warm-up table)
+        sf = step_flops(cfg, B)
+        roof["step"] = {"algo_flops": sf, "achieved_tflops": sf / (ms_step * 1e-3) / 1e12, "peak": PEAK[dtype],
+                        "frac": sf / (ms_step * 1e-3) / 1e12 / PEAK[dtype]}
+        wn, wk = widest_linear(cfg)
+        # (operand orientation, MxNxK) of the three products: forward x.W^T, input gradient dy.W, weight gradient dy^T.x
+        shapes = {"fwd": ("<0,0", f"[{B}x{wn}x{wk}]"), "dX": ("<0,1", f"[{B}x{wk}x{wn}]"), "dW": ("<1,1", f"[{wn}x{wk}x{B}]")}
+        wl = {}
+        for r in table:
+            for role, (ori, sh) in shapes.items():
+                if r["kernel"].startswith("gemm") and ori in r["kernel"] and r["kernel"].endswith(sh) and role not in wl and r["avg_ms"] > 0:
+                    tf = r["algo_flops"] / (r["avg_ms"] * 1e-3) / 1e12
+                    wl[role] = {"kernel": r["kernel"], "avg_us": r["avg_ms"] * 1e3, "tflops": tf, "frac": tf / (PEAK["f32"] if "f32" in r["kernel"] else PEAK[dtype])}
+        roof["widest_linear"] = {"layer": f"{wk}->{wn}", "source": "hipEvent brackets, warm-up steps (every launch timed)", **wl}
         out = {
             "metric": "glyphs/sec training (batch fwd+bwd+step)", "value": value, "unit": "glyphs/s", "n_gpus": world,
-            "steps": K, "warmup": W, "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak",
+            "steps": K, "warmup": W, "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": dtype, "data": "synthetic",
             "config": {"workload": DESCR[name], "per_gpu_batch": B, "global_batch": world * B,
                        "parallelism": f"dp{world}" if world > 1 else "single", "params": int(sum(n for _, _, _, n in eng.layout)),
                        "mean_loss": loss},
             "roofline": roof,
         }
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(name, cfg, B)
-            out["cpu_baseline"]["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
         if args.table:
             for r in table:
-                print(f"{r['kernel']:24s} n={r['launches']:4d} avg={r['avg_ms'] * 1e3:9.1f} us total={r['total_ms']:9.3f} ms", file=sys.stderr)
+                print(f"{r['kernel']:44s} n={r['launches']:4d} avg={r['avg_ms'] * 1e3:9.1f} us total={r['total_ms']:9.3f} ms", file=sys.stderr)
+    del eng
+    torch.cuda.empty_cache()
+    if world == 1 and rank == 0:
+        if not args.no_extras and not args.batch:
+            # parity mode of the SAME config (exact-f32 MFMA everywhere: the mode that meets the 1e-4 bitmap bar)
+            if dtype != "f32":
+                _, el, _, _, _ = measure(name, "f32", B, max(5, K // 4), 3, 0, 1, None, with_roofline=False)
+                kk = max(5, K // 4)
+                out["parity_mode"] = {"dtype": "f32", "ms_per_step": el / kk * 1e3, "value": B * kk / el, "unit": "glyphs/s", "steps": kk,
+                                      "note": "same workload with f32 operands (v_mfma_f32_32x32x2_f32); bitmaps within 2e-5 of the reference"}
+                torch.cuda.empty_cache()
+            if name == "c3":
+                # the reference's own model (R0) beside the headline config: sheets/s, bf16 throughput mode
+                rb = WORKLOADS["r0"]["batch"]
+                e2, el, d2, _, _ = measure("r0", "bf16", rb, 10, 3, 0, 1, None)
+                out["r0"] = {"workload": DESCR["r0"], "dtype": "bf16", "ms_per_step": el / 10 * 1e3, "value": rb * 10 / el, "unit": "sheets/s",
+                             "steps": 10, "dominant_kernel": d2["kernel"], "dominant_avg_ms": d2["avg_ms"],
+                             "dominant_hbm_GBs": d2["algo_bytes"] / (d2["avg_ms"] * 1e-3) / 1e9,
+                             "step_mfma_frac": step_flops(WORKLOADS["r0"]["cfg"], rb) / (el / 10) / 1e12 / PEAK["bf16"]}
+                del e2
+                torch.cuda.empty_cache()
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(name, cfg, B)
+            out["cpu_baseline"]["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
+    if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

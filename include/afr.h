@@ -169,6 +169,11 @@ int afr_op_gemm(int dtype, int flags, const void* A, const void* B, void* C, con
                 int splitk, void* stream);
 int afr_op_reduce(float* dst, const float* slabs, int nslabs, int64_t slab_stride, int64_t n,
                   float scale, int accumulate, void* stream);
+/* Several slab reductions in ONE launch (what a backward pass uses for all its split-K / per-block partial gradients):
+ * dst[i][0..n[i]) = sum_s slabs[i][s*stride[i] + ...], s < nslabs[i], fixed order.  At most 24 segments: more is an
+ * error (AFR_EINVAL), never a silent drop.  n[i] must be a multiple of 4. */
+int afr_op_reduce_group(int nseg, float* const* dst, const float* const* slabs, const int* nslabs,
+                        const int64_t* stride, const int64_t* n, void* stream);
 int afr_op_adamw(float* p, const float* g, float* m, float* v, void* shadow_bf16, int64_t n, float lr,
                  float beta1, float beta2, float eps, float weight_decay, int64_t t, float grad_scale,
                  void* stream);

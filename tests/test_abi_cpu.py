@@ -64,3 +64,35 @@ def test_bad_configs_are_rejected_with_a_message():
     assert lib.afr_plan_create(C.byref(c), C.byref(plan)) < 0
     with pytest.raises(_lib.AfrError):
         _lib.check(lib.afr_plan_create(C.byref(c), C.byref(plan)))
+
+
+def test_operands_of_2gib_or_more_are_rejected_not_silently_zero_filled():
+    """The bf16 LDS-DMA path addresses an operand with 32-bit byte offsets (gemm.hip make_rsrc / stage_inst): an operand of
+    2 GiB or more would read zeros past the limit.  Argument validation only -- nothing is launched."""
+    from ai_font_renderer_amd import _lib, config
+    from ai_font_renderer_amd.engine import make_afr_config
+    lib = _lib.lib()
+    fake = C.c_void_p(0x1000)
+    M, K = 32768, 32768                                           # 32768^2 bf16 = 2 GiB
+    rc = lib.afr_op_gemm(_lib.AFR_BF16, 0, fake, fake, fake, None, None, M, 1024, K, K, K, 1024, 0, 1, None)
+    assert rc == -4 and b"2 GiB" in lib.afr_last_error()          # AFR_EUNSUPPORTED
+    plan = C.c_void_p()
+    c = make_afr_config(config.SheetConfig(), "bf16", 60000)      # 60000 x 19200 bf16 activations = 2.3 GB
+    assert lib.afr_plan_create(C.byref(c), C.byref(plan)) == -4
+    assert b"2 GiB" in lib.afr_last_error()
+    c = make_afr_config(config.SheetConfig(), "f32", 60000)       # the f32 kernels index with 64-bit arithmetic
+    assert lib.afr_plan_create(C.byref(c), C.byref(plan)) == 0
+    lib.afr_plan_destroy(plan)
+
+
+def test_grouped_reduce_refuses_more_segments_than_it_can_hold():
+    """afr_rtable_add used to drop segment 25 silently (a gradient would have gone missing); now it is an error."""
+    from ai_font_renderer_amd import _lib
+    lib = _lib.lib()
+    n = 25
+    ptrs = (C.c_void_p * n)(*[0x1000] * n)
+    ns = (C.c_int * n)(*[2] * n)
+    st = (C.c_int64 * n)(*[64] * n)
+    ln = (C.c_int64 * n)(*[64] * n)
+    assert lib.afr_op_reduce_group(n, ptrs, ptrs, ns, st, ln, None) == -1      # AFR_EINVAL
+    assert b"at most 24" in lib.afr_last_error()

@@ -207,3 +207,21 @@ def test_glyph_first_layer_fold_edge_shapes(cfg, B, xmax):
 def test_glyph_fold_bf16_every_code_repeated():
     from .util import GlyphConfig
     _glyph_check(GlyphConfig(hidden=(64, 48), out_h=4, out_w=8, n_fonts=2), 1000, dtype="bf16", tol=3e-2, ytol=3e-2, xmax=128)
+
+
+def test_grouped_reduce_op_sums_each_segment_in_order():
+    """afr_op_reduce_group: several slab reductions in one launch (shallow and deep segments), each == the ordered sum."""
+    import ctypes as C
+    from ai_font_renderer_amd import _lib
+    lib = _lib.lib()
+    shapes = [(3, 4096), (40, 256), (8, 1000)]                 # (slabs, elements): 40 slabs takes the deep (4-wave) path
+    srcs = [torch.from_numpy(synth.hash_uniform(980 + i, (s, n), 1.0)).cuda() for i, (s, n) in enumerate(shapes)]
+    dsts = [torch.full((n,), float("nan"), device="cuda") for _, n in shapes]
+    k = len(shapes)
+    rc = lib.afr_op_reduce_group(k, (C.c_void_p * k)(*[d.data_ptr() for d in dsts]), (C.c_void_p * k)(*[s.data_ptr() for s in srcs]),
+                                 (C.c_int * k)(*[s for s, _ in shapes]), (C.c_int64 * k)(*[n for _, n in shapes]),
+                                 (C.c_int64 * k)(*[n for _, n in shapes]), C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0, lib.afr_last_error()
+    torch.cuda.synchronize()
+    for d, s in zip(dsts, srcs):
+        assert float((d.cpu().double() - s.cpu().double().sum(0)).abs().max()) < 1e-5

@@ -82,6 +82,48 @@ def test_autograd_path_matches_reference_gradients(mini_module):
     assert not torch.equal(before, m.state_dict()["fc1.bias"])
 
 
+def test_stock_torch_optimizer_in_bf16_mode_changes_the_next_forward():
+    """AFR_DTYPE=bf16: the GEMMs read a bf16 shadow of the f32 masters.  A stock torch optimiser steps the f32 Parameters
+    behind the engine's back; the module notices (tensor version counters) and re-derives the shadow, so the next forward
+    uses the new weights -- it used to keep training against the stale shadow, silently."""
+    from ai_font_renderer_amd import model as M
+    from ai_font_renderer_amd.engine import Engine
+    m = M.AttentionFontRenderer(max_length=10, dtype="bf16", max_batch=8, init=False)
+    m.engine.load_params(synth.make_params(m.config))
+    x = torch.from_numpy(synth.encode_strings(["HELLO WORL", "AB CD"], 10))
+    m.eval()
+    with torch.no_grad():
+        y0 = m(x).clone()
+        y0b = m(x).clone()
+    assert torch.equal(y0, y0b)
+    m.train()
+    out = m(x)
+    out.sum().backward()
+    torch.optim.SGD(m.parameters(), lr=0.5).step()
+    m.eval()
+    with torch.no_grad():
+        y1 = m(x).clone()
+    assert not torch.equal(y0, y1)
+    # and it is exactly the forward of a fresh bf16 engine holding the stepped parameters
+    ref = Engine(m.config, dtype="bf16", max_batch=8, device=M.device)
+    ref.load_params({k: v.detach() for k, v in m.state_dict().items()})
+    assert torch.equal(ref.forward(x), y1)
+
+
+def test_engine_on_an_explicit_device_index():
+    """Engine(device="cuda:0") with the guard in place: calls made under another stream context still land in order."""
+    from ai_font_renderer_amd.engine import Engine
+    eng = Engine(MINI, dtype="f32", max_batch=8, device="cuda:0")
+    eng.load_params(synth.make_params(MINI))
+    fx = load("sheet_mini.npz")
+    side = torch.cuda.Stream(device="cuda:0")
+    torch.cuda.synchronize()
+    with torch.cuda.stream(side):
+        y = eng.forward(torch.from_numpy(fx["x10"]))
+    side.synchronize()
+    assert maxabs(y.cpu().numpy(), fx["eval_y10"]) < 2e-5
+
+
 def test_render_strings_writes_the_reference_bitmaps(tmp_path):
     """15 test_strings -> string_{i}.bmp: 8-bit BMPs whose pixels are the reference's (a*255).astype(uint8) +-1."""
     from PIL import Image

@@ -98,3 +98,36 @@ def test_product_never_imports_the_oracle():
     for f in files:
         src = open(f).read()
         assert "import oracle" not in src and "from oracle" not in src and "afr_oracle" not in src, f
+
+
+def test_engine_calls_run_on_the_engines_device_and_its_stream(monkeypatch):
+    """An Engine on cuda:k must enqueue on cuda:k's current stream with cuda:k current, whatever the process's current
+    device is (LOCAL_RANK != 0 without a set_device used to launch every kernel on GPU 0's stream).  No GPU needed: the
+    guard and the stream lookup are observed through stand-ins."""
+    import contextlib
+    import ctypes as C
+    from ai_font_renderer_amd import engine as E
+    seen = []
+
+    class FakeStream:
+        def __init__(self, dev):
+            self.cuda_stream = 0x5000 + (dev.index if dev is not None else 99)
+
+    @contextlib.contextmanager
+    def fake_device(dev):
+        seen.append(("enter", dev))
+        yield
+        seen.append(("exit", dev))
+
+    monkeypatch.setattr(torch.cuda, "device", fake_device)
+    monkeypatch.setattr(torch.cuda, "current_stream", lambda device=None: FakeStream(device))
+    eng = E.Engine.__new__(E.Engine)
+    eng.device = torch.device("cuda", 3)
+
+    def fn(a, b, stream):
+        seen.append(("call", a, b, stream.value))
+        return 0
+
+    eng._call(fn, 1, 2)
+    assert seen == [("enter", eng.device), ("call", 1, 2, 0x5003), ("exit", eng.device)]
+    eng.__dict__.clear()                                       # nothing for __del__ to tear down
