@@ -66,6 +66,12 @@ struct afr_plan {
     char* ws = nullptr;
     size_t ws_bytes = 0, ws_need = 0;
     int device = -1;               // the GPU that owns the bound buffers (afr_bind)
+    // products collected for ONE grouped launch (a layer's weight gradient + input gradient): see flush_gemms
+    bool defer = false;
+    int pend_tile256 = 0;
+    std::vector<GemmParams> pend;
+    std::vector<std::string> pend_tag;
+    double pend_flops = 0.0, pend_bytes = 0.0;
     // workspace offsets (bytes)
     size_t o_shadow = 0, o_err = 0, o_loss = 0, o_u = 0, o_z = 0, o_dz = 0, o_slab_e = 0, o_save = 0;
     std::vector<size_t> o_act;     // glyph: activations h0..h_nh
@@ -462,17 +468,41 @@ static int run_gemm(afr_plan* p, hipStream_t s, int flags, const void* A, const 
     const double out_bytes = fa ? (double)M * N * (24.0 + (fa->shadow ? 2.0 : 0.0)) : (splitk > 1 ? 4.0 : ob) * (double)M * N;
     char tag[96];
     snprintf(tag, sizeof tag, "%s[%dx%dx%d]", afr_gemm_kernel_name(p->cfg.dtype, g), M, N, K);
-    ProfScope ps(p, s, tag, 2.0 * M * (double)N * K, eb * ((double)M * K + (double)N * K) + out_bytes);
+    const double fl_ = 2.0 * M * (double)N * K, by_ = eb * ((double)M * K + (double)N * K) + out_bytes;
+    if (p->defer && afr_gemm_groupable(p->cfg.dtype, g) && p->pend.size() < 4) {
+        p->pend.push_back(g); p->pend_tag.push_back(tag); p->pend_flops += fl_; p->pend_bytes += by_;
+        return AFR_OK;
+    }
+    ProfScope ps(p, s, tag, fl_, by_);
     HIPCHK(afr_launch_gemm(p->cfg.dtype, g, s));
+    return AFR_OK;
+}
+// launch what run_gemm collected while p->defer was set: one grouped launch (or the plain one when only one qualified)
+static int flush_gemms(afr_plan* p, hipStream_t s) {
+    p->defer = false;
+    if (p->pend.empty()) return AFR_OK;
+    std::string tag = p->pend.size() > 1 ? (p->pend_tile256 ? "gemm_bf16_group256" : "gemm_bf16_group") : p->pend_tag[0];
+    if (p->pend.size() > 1) {
+        tag += "[";
+        for (size_t i = 0; i < p->pend_tag.size(); ++i) tag += (i ? "+" : "") + p->pend_tag[i].substr(p->pend_tag[i].find('[') + 1, p->pend_tag[i].find(']') - p->pend_tag[i].find('[') - 1);
+        tag += "]";
+    }
+    hipError_t e;
+    {
+        ProfScope ps(p, s, tag.c_str(), p->pend_flops, p->pend_bytes);
+        e = afr_launch_gemm_group(p->cfg.dtype, p->pend.data(), (int)p->pend.size(), p->pend_tile256, s);
+    }
+    p->pend.clear(); p->pend_tag.clear(); p->pend_flops = p->pend_bytes = 0.0;
+    if (e != hipSuccess) return fail(AFR_EHIP, "grouped GEMM launch: %s", hipGetErrorString(e));
     return AFR_OK;
 }
 // dW[N][K] = dy[B][N]^T . a[B][K] and db[N] = sum_b dy, reduced over the batch in ONE GEMM launch (the bias gradient
 // is the column sum of the A tiles the kernel already stages).  Small outputs use split-K partial slabs, summed later
 // by the grouped reduce; large ones (fc_output of the sheet model) write the gradient buffer directly.
-static int run_dw(afr_plan* p, hipStream_t s, const afr_plan::Layer& l, const void* dy, const void* a, int Bn, RTable& rt) {
+static int run_dw(afr_plan* p, hipStream_t s, const afr_plan::Layer& l, const void* dy, const void* a, int Bn, RTable& rt, int sk_want = 0) {
     const int fl = AFR_GEMM_A_KSTRIDED | AFR_GEMM_B_KSTRIDED;
     const int N = l.N, K = l.K;
-    int sk = choose_splitk(N, K, Bn);
+    int sk = sk_want > 0 ? sk_want : choose_splitk(N, K, Bn);
     if (sk > l.sk) sk = l.sk;
     if (sk == 1) return run_gemm(p, s, fl, dy, a, p->G + l.w_off, nullptr, nullptr, N, K, Bn, N, K, K, 0, 1, 0, p->G + l.b_off, 0);
     float* sw = (float*)(p->ws + l.o_slab_w);
@@ -707,11 +737,24 @@ static int backward_stage_impl(afr_plan* p, int stage, int64_t* g_off, int64_t* 
         if (g_len) *g_len = l.b_off + (l.N + 63) / 64 * 64;
         return AFR_OK;
     }
-    if ((rc = run_dw(p, s, l, dy, a, B, rt))) return rc;
+    // A layer's two gradient products both consume dy and are independent: when the input-gradient product alone fills the
+    // chip with 256x128 tiles they go out as ONE grouped launch, the weight gradient first and split so that one of its
+    // blocks runs twice the K-tiles of an input-gradient block (half the slabs of the stand-alone choice; a CU draws
+    // either one long block or two short ones).
+    int sk_group = 0, tile256 = 0;
+    if (c.dtype == AFR_BF16 && !(c.reserved & 2)) {
+        const long long dx_tiles = (long long)((B + 255) / 256) * ((l.K + 127) / 128);
+        if (dx_tiles >= 232 && l.N >= 256) afr_gemm_pair_plan(B, l.N, l.K, &tile256, &sk_group);
+        if (sk_group > l.sk) { sk_group = 0; tile256 = 0; }          // the plan's slab space bounds the split
+    }
+    p->pend_tile256 = tile256;
+    p->defer = sk_group > 0;
+    if ((rc = run_dw(p, s, l, dy, a, B, rt, sk_group))) { p->defer = false; p->pend.clear(); p->pend_tag.clear(); p->pend_flops = p->pend_bytes = 0.0; return rc; }
     void* dx = p->ws + p->o_d[stage & 1];
     const int fl = AFR_GEMM_B_KSTRIDED | ob | (i > 0 ? AFR_GEMM_RELU_MASK : 0);
     if ((rc = run_gemm(p, s, fl, dy, weight_ptr(p, l.w_off), dx, nullptr, i > 0 ? a : nullptr, B, l.K, l.N, l.N, l.K, l.K,
-                       l.K, 1, 0))) return rc;
+                       l.K, 1, 0))) { p->defer = false; p->pend.clear(); p->pend_tag.clear(); p->pend_flops = p->pend_bytes = 0.0; return rc; }
+    if ((rc = flush_gemms(p, s))) return rc;
     const int64_t end = l.b_off + (l.N + 63) / 64 * 64;
     if (i > 0) {
         if ((rc = flush())) return rc;

@@ -124,6 +124,10 @@ __device__ __forceinline__ void adamw_elem(float& p, float& m, float& v, float g
     p -= step_size * (m / denom);
 }
 hipError_t afr_launch_gemm(int dtype, const GemmParams& p, hipStream_t s);
+// several independent products in one launch (falls back to one launch each when one of them does not qualify)
+bool afr_gemm_groupable(int dtype, const GemmParams& p);
+hipError_t afr_launch_gemm_group(int dtype, const GemmParams* ps, int n, int tile256, hipStream_t s);
+void afr_gemm_pair_plan(int B, int n_out, int k_in, int* tile256, int* splitk);
 const char* afr_gemm_kernel_name(int dtype, const GemmParams& p);
 
 hipError_t afr_launch_reduce(float* dst, const float* slabs, int nslabs, long long slab_stride, long long n,

@@ -27,8 +27,7 @@
 // indices... i.e. the 8 big-operand tiles of a group stay hot while the small operand is swept once per GROUP rather
 // than once per slow index (R0's dW GEMM re-read its 13 MB activation operand 75x, 1 GB of extra HBM reads per step,
 // before this).  Placement changes speed only, never results.
-__device__ __forceinline__ void tile_of_block(const GemmParams& p, int BM, int BN, int& tm, int& tn, int& z) {
-    const int nb = gridDim.x, b = blockIdx.x;
+__device__ __forceinline__ void tile_of_block(const GemmParams& p, int BM, int BN, int b, int nb, int& tm, int& tn, int& z) {
     const int q = nb >> 3, r = nb & 7, xcd = b & 7, idx = b >> 3;
     const int v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
@@ -105,7 +104,7 @@ __global__ __launch_bounds__(256) void gemm_f32(GemmParams p) {
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid >> 1, wn = wid & 1;
     int tm, tn, z;
-    tile_of_block(p, BM, BN, tm, tn, z);
+    tile_of_block(p, BM, BN, blockIdx.x, gridDim.x, tm, tn, z);
     const int m0 = tm * BM, n0 = tn * BN;
     const int klen = ((p.K + p.splitk - 1) / p.splitk + BK - 1) / BK * BK;
     const int kbeg = z * klen;
@@ -254,6 +253,23 @@ __device__ __forceinline__ i32x4 make_rsrc(const void* base) {
     i32x4 r = {(int)(unsigned)a, (int)((unsigned)(a >> 32) & 0xFFFFu), 0x7FFFFFFF, 0x00020000};
     return r;
 }
+// byte offset of lane `lane`'s 16 source bytes of piece `inst` of a sub-tile (out of range -> past the descriptor: zeros)
+template <int LAY>
+__device__ __forceinline__ unsigned piece_voff(int ld, int X, int x0, int k0, int kend, int inst, int lane) {
+    int gx, gk;
+    if (LAY == 0) {
+        const int r = inst * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ (r & 7);
+        gx = x0 + r; gk = k0 + 8 * c;
+    } else {
+        const int kr = inst * 4 + (lane >> 4);
+        const int c = (lane & 15) ^ (fswz(kr) << 1);
+        gk = k0 + kr; gx = x0 + 8 * c;
+    }
+    unsigned off = (LAY == 0) ? (unsigned)(((size_t)gx * ld + gk) * 2) : (unsigned)(((size_t)gk * ld + gx) * 2);
+    if (gx >= X || gk >= kend) off = 0x80000000u;
+    return off;
+}
 template <int LAY>
 __device__ __forceinline__ void stage_inst(i32x4 rsrc, unsigned lds_sub, int ld, int X, int x0, int k0,
                                            int kend, int inst, int lane) {
@@ -312,17 +328,178 @@ __device__ __forceinline__ void nt_st4(float* q, float4 v) {
 // ids, in a buffer of its own (tools/gemm_timeline.py); no output value depends on them.
 #ifdef AFR_GEMM_TIMING
 __device__ unsigned long long* g_gemm_stamps = nullptr;
-#define GSTAMP(i) do { if (stamps && tid == 0) stamps[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define GSTAMP(i) do { if (stamps && tid == 0) stamps[bid * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define GSTAMP(i) do { } while (0)
 #endif
+// The epilogue of one wave's 64x64 f32 accumulator tile whose top-left element is (mb, nb0) of the product; Wt = the
+// wave's own 16 KiB of LDS.  Shared by the 256x128 / 128x128 kernels (one call) and the 256x256 kernel (two calls).
 template <int ALAY, int BLAY, int WM>
-__global__ __launch_bounds__(128 * WM, 2) void gemm_bf16(GemmParams p) {
+__device__ __forceinline__ void wave_epilogue(const GemmParams& p, const f32x4 (&acc)[4][4], const int mb, const int nb0, const int z,
+                                              float* Wt, const int lane, float& lsum) {
+    // Epilogue through LDS: the MFMA accumulators hold 4 consecutive n of 16 different rows per lane-group, which as
+    // direct stores would be 32-byte pieces.  Each wave parks its 64x64 f32 tile in its own 16 KiB of LDS (16-B chunks
+    // XOR-swizzled by row: conflict-free both ways) and streams it out row-contiguous: 8 lanes x 8 values = one 64-col
+    // row, so stores (and the aux / target loads of the fused tails) are whole 128-B / 256-B row segments.
+    const int flags = p.flags;
+    const bool out_bf16 = flags & AFR_GEMM_OUT_BF16;
+    const bool mse = p.mse_target != nullptr;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int ml = 16 * i + (lane & 15);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int nl = 16 * j + 4 * (lane >> 4);
+            const int n = nb0 + nl;
+            f32x4 v = acc[i][j];
+            if ((flags & AFR_GEMM_BIAS) && n < p.N) {
+                const float4 bb = *reinterpret_cast<const float4*>(p.bias + n);
+                v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
+            }
+            if (flags & AFR_GEMM_RELU) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+            }
+            *reinterpret_cast<f32x4*>(Wt + ml * 64 + (((nl >> 2) ^ (ml & 15)) << 2)) = v;
+        }
+    }
+    float* Cf = reinterpret_cast<float*>(p.C) + (size_t)z * p.slab_stride;
+    bf16_t* Cb = reinterpret_cast<bf16_t*>(p.C);
+    const bf16_t* aux = reinterpret_cast<const bf16_t*>(p.aux);
+    const float g2 = 2.f * p.mse_inv_n;
+    const int c8 = lane & 7;
+    const int n = nb0 + 8 * c8;
+    const bool ncol = n < p.N;
+    const bool relu_mask = flags & AFR_GEMM_RELU_MASK;
+    // the tails' global operands (aux for the ReLU mask, targets for the fused loss) are fetched for all 8 row passes
+    // up front: one memory latency instead of eight serial ones
+    bf16x8 auxv[8];
+    uint2 tu8[8];
+    if (relu_mask || (mse && p.mse_target_dtype == AFR_TARGET_U8)) {
+#pragma unroll
+        for (int ps = 0; ps < 8; ++ps) {
+            const int m = mb + ps * 8 + (lane >> 3);
+            if (m < p.M && ncol) {
+                if (relu_mask) auxv[ps] = *reinterpret_cast<const bf16x8*>(aux + (size_t)m * p.ldaux + n);
+                if (mse) tu8[ps] = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint8_t*>(p.mse_target) + (size_t)m * p.N + n);
+            }
+        }
+    }
+    if (!out_bf16) {
+        // f32 outputs (split-K slabs, direct gradients, fused AdamW): 16 lanes x 16 B cover one 64-column row, so every
+        // wave-instruction moves four whole 256-B row segments (with 8 columns per lane as below, an f32 row would be
+        // written and read as two interleaved half-filled passes over the same cache lines).  16 passes of 4 rows.
+        // Fused AdamW (weight-gradient GEMMs only): p, m, v of the wave's 64x64 tile are 16 passes x 3 x 16 B per lane.  Such a launch is
+        // bound by how many of those loads a CU keeps in flight (measured on R0: 770 / 745 / 726 / 713 us with 3 / 7 / 11 / 15
+        // passes ahead), so the 4-wave kernel (256 VGPRs per lane) keeps 13 of the 16 passes in flight from the moment the accumulators are parked
+        // in LDS.  (Issuing some before the K loop was slower: vmcnt is in-order, so the ring's counted waits then also wait
+        // for these HBM loads.)
+        constexpr bool ADAM = (ALAY == 1 && BLAY == 1);
+        constexpr int ADF = !ADAM ? 1 : (WM == 2) ? 14 : 4;    // 14: the deepest that allocates without scratch
+        const int c4 = lane & 15;
+        const int nf = nb0 + 4 * c4;
+        const bool okc = nf < p.N;
+        float4 qp[ADF], qm[ADF], qv[ADF];
+        auto load_f = [&](int ps, int buf) {
+            const int m = mb + ps * 4 + (lane >> 4);
+            if (m < p.M && okc) {
+                const size_t wi = (size_t)m * p.ldc + nf;
+                qp[buf] = ADLD(p.ad_p + wi); qm[buf] = ADLD(p.ad_m + wi); qv[buf] = ADLD(p.ad_v + wi);
+            }
+        };
+        const bool adam = ADAM && p.ad_p != nullptr;
+        if (adam) {
+#pragma unroll
+            for (int q = 0; q < ADF - 1; ++q) load_f(q, q);
+        }
+#pragma unroll
+        for (int ps = 0; ps < 16; ++ps) {
+            const int rl = ps * 4 + (lane >> 4);
+            if (adam && ps + ADF - 1 < 16) load_f(ps + ADF - 1, (ps + ADF - 1) % ADF);
+            f32x4 g = *reinterpret_cast<const f32x4*>(Wt + rl * 64 + ((c4 ^ (rl & 15)) << 2));
+            const int m = mb + rl;
+            if (m >= p.M || !okc) continue;
+            const size_t wi = (size_t)m * p.ldc + nf;
+            if (relu_mask) {                            // only the op-level API combines the mask with f32 output
+                const bf16x4 a = *reinterpret_cast<const bf16x4*>(aux + (size_t)m * p.ldaux + nf);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) g[r] = ((float)a[r] > 0.f) ? g[r] : 0.f;
+            }
+            if (adam) {
+                const int bf = ps % ADF;
+                float pp[4] = {qp[bf].x, qp[bf].y, qp[bf].z, qp[bf].w}, mm[4] = {qm[bf].x, qm[bf].y, qm[bf].z, qm[bf].w};
+                float vv[4] = {qv[bf].x, qv[bf].y, qv[bf].z, qv[bf].w};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) adamw_elem(pp[r], mm[r], vv[r], g[r], p.ad_decay, p.ad_b1, p.ad_b2, p.ad_eps, p.ad_step, p.ad_rsqrt_bc2);
+                ADST(p.ad_p + wi, make_float4(pp[0], pp[1], pp[2], pp[3]));
+                ADST(p.ad_m + wi, make_float4(mm[0], mm[1], mm[2], mm[3]));
+                ADST(p.ad_v + wi, make_float4(vv[0], vv[1], vv[2], vv[3]));
+                if (p.ad_shadow) {
+                    bf16x4 o = {(bf16_t)pp[0], (bf16_t)pp[1], (bf16_t)pp[2], (bf16_t)pp[3]};
+                    __builtin_nontemporal_store(o, reinterpret_cast<bf16x4*>(p.ad_shadow + wi));
+                }
+            } else {
+                nt_st4(Cf + wi, make_float4(g[0], g[1], g[2], g[3]));
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int ps = 0; ps < 8; ++ps) {
+        const int rl = ps * 8 + (lane >> 3);
+        const f32x4 lo = *reinterpret_cast<const f32x4*>(Wt + rl * 64 + (((2 * c8) ^ (rl & 15)) << 2));
+        const f32x4 hi = *reinterpret_cast<const f32x4*>(Wt + rl * 64 + (((2 * c8 + 1) ^ (rl & 15)) << 2));
+        float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        const int m = mb + rl;
+        if (m >= p.M || !ncol) continue;
+        if (relu_mask) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) v[r] = ((float)auxv[ps][r] > 0.f) ? v[r] : 0.f;
+        }
+        if (mse) {
+            float t[8];
+            const size_t ti = (size_t)m * p.N + n;
+            if (p.mse_target_dtype == AFR_TARGET_U8) {
+                const uint2 w = tu8[ps];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { t[r] = (float)((w.x >> (8 * r)) & 0xFF) / 255.0f; t[4 + r] = (float)((w.y >> (8 * r)) & 0xFF) / 255.0f; }
+            } else {
+                const float4 w0 = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.mse_target) + ti);
+                const float4 w1 = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.mse_target) + ti + 4);
+                t[0] = w0.x; t[1] = w0.y; t[2] = w0.z; t[3] = w0.w; t[4] = w1.x; t[5] = w1.y; t[6] = w1.z; t[7] = w1.w;
+            }
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const float u = out_bf16 ? (float)(bf16_t)v[r] : v[r];     // the value the unfused path would store
+                const float diff = fminf(fmaxf(u, 0.f), 1.f) - t[r];
+                lsum += diff * diff;
+                v[r] = (u >= 0.f && u <= 1.f) ? g2 * diff : 0.f;
+            }
+        }
+        {
+            bf16x8 o;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) o[r] = (bf16_t)v[r];
+            // streaming stores: a kernel's dirty L2 lines are written back at its end, before the next kernel may start
+            // (the XCDs' L2s are not coherent with each other); write-through output leaves nothing to drain (C3 -3.7 %)
+            __builtin_nontemporal_store(o, reinterpret_cast<bf16x8*>(Cb + (size_t)m * p.ldc + n));
+        }
+    }
+}
+
+template <int WM> struct RingGeom {
+    static constexpr int ASUB = WM / 2, STAGES = (WM == 4) ? 3 : 2, STAGE_BYTES = (ASUB + 1) * SUB, LDS_BYTES = STAGES * STAGE_BYTES;
+};
+// One output tile (and k-split) of one product: block `bid` of the `nblk` blocks that product was given.  A plain launch
+// passes its own blockIdx / gridDim; a grouped launch (gemm_bf16_group) a sub-range of its grid.
+// ABL (kernel-development builds only, -DAFR_GEMM_LAB): ablation bits for the ring loop -- 1: no DMA inside the loop,
+// 2: no fragment reads inside the loop, 4: no MFMAs.  Results are wrong by construction; only the time is read.
+template <int ALAY, int BLAY, int WM, int ABL = 0>
+__device__ __forceinline__ void gemm_bf16_body(const GemmParams& p, const int bid, const int nblk, char* smem) {
     constexpr int BM = 64 * WM, NW = 2 * WM, ASUB = WM / 2;
-    constexpr int STAGES = (WM == 4) ? 3 : 2;
-    constexpr int STAGE_BYTES = (ASUB + 1) * SUB;
+    constexpr int STAGES = RingGeom<WM>::STAGES;
+    constexpr int STAGE_BYTES = RingGeom<WM>::STAGE_BYTES;
     constexpr int A_PER_WAVE = ASUB * 16 / NW, B_PER_WAVE = 16 / NW;
-    __shared__ __attribute__((aligned(16))) char smem[STAGES * STAGE_BYTES];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
@@ -333,11 +510,12 @@ __global__ __launch_bounds__(128 * WM, 2) void gemm_bf16(GemmParams p) {
         unsigned xcc, hwid;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-        stamps[blockIdx.x * 8 + 4] = xcc; stamps[blockIdx.x * 8 + 5] = hwid;
+        stamps[bid * 8 + 4] = xcc; stamps[bid * 8 + 5] = hwid;
     }
 #endif
     int tm, tn, z;
-    tile_of_block(p, BM, BN, tm, tn, z);
+    tile_of_block(p, BM, BN, bid, nblk, tm, tn, z);
+    if (z >= p.splitk) return;                       // padding block of a grouped launch (ranges are rounded up to 8)
     const int m0 = tm * BM, n0 = tn * BN;
     const int klen = ((p.K + p.splitk - 1) / p.splitk + BK - 1) / BK * BK;
     const int kbeg = z * klen;
@@ -414,14 +592,18 @@ __global__ __launch_bounds__(128 * WM, 2) void gemm_bf16(GemmParams p) {
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
+            if constexpr (!(ABL & 4)) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
-            if (do_stage) {
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+            } else {
+                asm volatile("" ::"v"(fa[i]), "v"(fb[i]));
+            }
+            if (do_stage && !(ABL & 1)) {
 #pragma unroll
                 for (int q = i * NP / 4; q < (i + 1) * NP / 4; ++q) stage_piece(tn, slot, q);
             }
-            if (do_read) {
+            if (do_read && !(ABL & 2)) {
                 ra[i] = read_frag<ALAY>(Sn + (wm >> 1) * SUB, (wm & 1) * 64 + 16 * i, ks, lane);
                 rb[i] = read_frag<BLAY>(Sn + ASUB * SUB, wn * 64 + 16 * i, ks, lane);
             }
@@ -472,13 +654,30 @@ __global__ __launch_bounds__(128 * WM, 2) void gemm_bf16(GemmParams p) {
         for (int t = 0; t < nt; ++t) {
             const char* S = smem + slot * STAGE_BYTES;
             if (ALAY == 1 && do_cs) colsum_tile(S);
-            mma_mem(a0, b0, false, 0, 0, true, S, 1, a1, b1);                     // A inside B
+            if ((ABL & 8) && wave >= 4) {
+                // waves 4..7 (the SIMD partners of 0..3) re-fill the ring in the FIRST half of an iteration, waves 0..3 in
+                // the second: at any time only one of a SIMD's two waves is issuing DMA (an LDS-DMA piece holds its wave for
+                // ~100 cycles), the other has bare MFMAs + LDS reads for the matrix pipe.  Slot (t+2)%3 held tile t-1, which
+                // every wave finished reading before the barrier of iteration t-1.
+                int ps = slot + 2; if (ps >= 3) ps -= 3;
+                mma_mem(a0, b0, t >= 1 && t + 2 < nt, t + 2, ps, true, S, 1, a1, b1);
+            } else {
+                mma_mem(a0, b0, false, 0, 0, true, S, 1, a1, b1);                     // A inside B
+            }
             if (t + 1 < nt) {
-                if (t + 2 < nt) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");   // C
-                else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                if ((ABL & 8) && wave >= 4) {
+                    // outstanding here: tile t+1 (6 pieces, issued one iteration ago) and tile t+2 (just issued)
+                    if (t >= 1 && t + 2 < nt) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+                    else if (t == 0 && nt > 2) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");   // prologue's tiles 1, 2
+                    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                } else {
+                    if (t + 2 < nt) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");   // C
+                    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                }
                 __builtin_amdgcn_s_barrier();
                 int ns = slot + 1; if (ns == 3) ns = 0;
-                mma_mem(a1, b1, t + 3 < nt, t + 3, slot, true, smem + ns * STAGE_BYTES, 0, a0, b0);   // D, E inside F
+                if ((ABL & 8) && wave >= 4) mma_mem(a1, b1, false, 0, 0, true, smem + ns * STAGE_BYTES, 0, a0, b0);
+                else mma_mem(a1, b1, t + 3 < nt, t + 3, slot, true, smem + ns * STAGE_BYTES, 0, a0, b0);   // D, E inside F
                 slot = ns;
             } else {
                 mma(a1, b1);
@@ -527,161 +726,9 @@ __global__ __launch_bounds__(128 * WM, 2) void gemm_bf16(GemmParams p) {
         }
         __syncthreads();                       // the staging below reuses this LDS
     }
-    // Epilogue through LDS: the MFMA accumulators hold 4 consecutive n of 16 different rows per lane-group, which as
-    // direct stores would be 32-byte pieces.  Each wave parks its 64x64 f32 tile in its own 16 KiB of LDS (16-B chunks
-    // XOR-swizzled by row: conflict-free both ways) and streams it out row-contiguous: 8 lanes x 8 values = one 64-col
-    // row, so stores (and the aux / target loads of the fused tails) are whole 128-B / 256-B row segments.
-    const int flags = p.flags;
-    const bool out_bf16 = flags & AFR_GEMM_OUT_BF16;
     const bool mse = p.mse_target != nullptr;
-    float* Wt = reinterpret_cast<float*>(smem) + wave * 4096;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int ml = 16 * i + (lane & 15);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int nl = 16 * j + 4 * (lane >> 4);
-            const int n = n0 + wn * 64 + nl;
-            f32x4 v = acc[i][j];
-            if ((flags & AFR_GEMM_BIAS) && n < p.N) {
-                const float4 bb = *reinterpret_cast<const float4*>(p.bias + n);
-                v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
-            }
-            if (flags & AFR_GEMM_RELU) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
-            }
-            *reinterpret_cast<f32x4*>(Wt + ml * 64 + (((nl >> 2) ^ (ml & 15)) << 2)) = v;
-        }
-    }
-    float* Cf = reinterpret_cast<float*>(p.C) + (size_t)z * p.slab_stride;
-    bf16_t* Cb = reinterpret_cast<bf16_t*>(p.C);
-    const bf16_t* aux = reinterpret_cast<const bf16_t*>(p.aux);
     float lsum = 0.f;
-    const float g2 = 2.f * p.mse_inv_n;
-    const int c8 = lane & 7;
-    const int n = n0 + wn * 64 + 8 * c8;
-    const bool ncol = n < p.N;
-    const bool relu_mask = flags & AFR_GEMM_RELU_MASK;
-    // the tails' global operands (aux for the ReLU mask, targets for the fused loss) are fetched for all 8 row passes
-    // up front: one memory latency instead of eight serial ones
-    bf16x8 auxv[8];
-    uint2 tu8[8];
-    if (relu_mask || (mse && p.mse_target_dtype == AFR_TARGET_U8)) {
-#pragma unroll
-        for (int ps = 0; ps < 8; ++ps) {
-            const int m = m0 + wm * 64 + ps * 8 + (lane >> 3);
-            if (m < p.M && ncol) {
-                if (relu_mask) auxv[ps] = *reinterpret_cast<const bf16x8*>(aux + (size_t)m * p.ldaux + n);
-                if (mse) tu8[ps] = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint8_t*>(p.mse_target) + (size_t)m * p.N + n);
-            }
-        }
-    }
-    if (!out_bf16) {
-        // f32 outputs (split-K slabs, direct gradients, fused AdamW): 16 lanes x 16 B cover one 64-column row, so every
-        // wave-instruction moves four whole 256-B row segments (with 8 columns per lane as below, an f32 row would be
-        // written and read as two interleaved half-filled passes over the same cache lines).  16 passes of 4 rows.
-        // Fused AdamW (weight-gradient GEMMs only): p, m, v of the wave's 64x64 tile are 16 passes x 3 x 16 B per lane.  Such a launch is
-        // bound by how many of those loads a CU keeps in flight (measured on R0: 770 / 745 / 726 / 713 us with 3 / 7 / 11 / 15
-        // passes ahead), so the 4-wave kernel (256 VGPRs per lane) keeps 13 of the 16 passes in flight from the moment the accumulators are parked
-        // in LDS.  (Issuing some before the K loop was slower: vmcnt is in-order, so the ring's counted waits then also wait
-        // for these HBM loads.)
-        constexpr bool ADAM = (ALAY == 1 && BLAY == 1);
-        constexpr int ADF = !ADAM ? 1 : (WM == 2) ? 14 : 4;    // 14: the deepest that allocates without scratch
-        const int c4 = lane & 15;
-        const int nf = n0 + wn * 64 + 4 * c4;
-        const bool okc = nf < p.N;
-        float4 qp[ADF], qm[ADF], qv[ADF];
-        auto load_f = [&](int ps, int buf) {
-            const int m = m0 + wm * 64 + ps * 4 + (lane >> 4);
-            if (m < p.M && okc) {
-                const size_t wi = (size_t)m * p.ldc + nf;
-                qp[buf] = ADLD(p.ad_p + wi); qm[buf] = ADLD(p.ad_m + wi); qv[buf] = ADLD(p.ad_v + wi);
-            }
-        };
-        const bool adam = ADAM && p.ad_p != nullptr;
-        if (adam) {
-#pragma unroll
-            for (int q = 0; q < ADF - 1; ++q) load_f(q, q);
-        }
-#pragma unroll
-        for (int ps = 0; ps < 16; ++ps) {
-            const int rl = ps * 4 + (lane >> 4);
-            if (adam && ps + ADF - 1 < 16) load_f(ps + ADF - 1, (ps + ADF - 1) % ADF);
-            f32x4 g = *reinterpret_cast<const f32x4*>(Wt + rl * 64 + ((c4 ^ (rl & 15)) << 2));
-            const int m = m0 + wm * 64 + rl;
-            if (m >= p.M || !okc) continue;
-            const size_t wi = (size_t)m * p.ldc + nf;
-            if (relu_mask) {                            // only the op-level API combines the mask with f32 output
-                const bf16x4 a = *reinterpret_cast<const bf16x4*>(aux + (size_t)m * p.ldaux + nf);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) g[r] = ((float)a[r] > 0.f) ? g[r] : 0.f;
-            }
-            if (adam) {
-                const int bf = ps % ADF;
-                float pp[4] = {qp[bf].x, qp[bf].y, qp[bf].z, qp[bf].w}, mm[4] = {qm[bf].x, qm[bf].y, qm[bf].z, qm[bf].w};
-                float vv[4] = {qv[bf].x, qv[bf].y, qv[bf].z, qv[bf].w};
-#pragma unroll
-                for (int r = 0; r < 4; ++r) adamw_elem(pp[r], mm[r], vv[r], g[r], p.ad_decay, p.ad_b1, p.ad_b2, p.ad_eps, p.ad_step, p.ad_rsqrt_bc2);
-                ADST(p.ad_p + wi, make_float4(pp[0], pp[1], pp[2], pp[3]));
-                ADST(p.ad_m + wi, make_float4(mm[0], mm[1], mm[2], mm[3]));
-                ADST(p.ad_v + wi, make_float4(vv[0], vv[1], vv[2], vv[3]));
-                if (p.ad_shadow) {
-                    bf16x4 o = {(bf16_t)pp[0], (bf16_t)pp[1], (bf16_t)pp[2], (bf16_t)pp[3]};
-                    __builtin_nontemporal_store(o, reinterpret_cast<bf16x4*>(p.ad_shadow + wi));
-                }
-            } else {
-                nt_st4(Cf + wi, make_float4(g[0], g[1], g[2], g[3]));
-            }
-        }
-#ifdef AFR_GEMM_TIMING
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        GSTAMP(3);
-#endif
-        return;
-    }
-#pragma unroll
-    for (int ps = 0; ps < 8; ++ps) {
-        const int rl = ps * 8 + (lane >> 3);
-        const f32x4 lo = *reinterpret_cast<const f32x4*>(Wt + rl * 64 + (((2 * c8) ^ (rl & 15)) << 2));
-        const f32x4 hi = *reinterpret_cast<const f32x4*>(Wt + rl * 64 + (((2 * c8 + 1) ^ (rl & 15)) << 2));
-        float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        const int m = m0 + wm * 64 + rl;
-        if (m >= p.M || !ncol) continue;
-        if (relu_mask) {
-#pragma unroll
-            for (int r = 0; r < 8; ++r) v[r] = ((float)auxv[ps][r] > 0.f) ? v[r] : 0.f;
-        }
-        if (mse) {
-            float t[8];
-            const size_t ti = (size_t)m * p.N + n;
-            if (p.mse_target_dtype == AFR_TARGET_U8) {
-                const uint2 w = tu8[ps];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) { t[r] = (float)((w.x >> (8 * r)) & 0xFF) / 255.0f; t[4 + r] = (float)((w.y >> (8 * r)) & 0xFF) / 255.0f; }
-            } else {
-                const float4 w0 = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.mse_target) + ti);
-                const float4 w1 = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.mse_target) + ti + 4);
-                t[0] = w0.x; t[1] = w0.y; t[2] = w0.z; t[3] = w0.w; t[4] = w1.x; t[5] = w1.y; t[6] = w1.z; t[7] = w1.w;
-            }
-#pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                const float u = out_bf16 ? (float)(bf16_t)v[r] : v[r];     // the value the unfused path would store
-                const float diff = fminf(fmaxf(u, 0.f), 1.f) - t[r];
-                lsum += diff * diff;
-                v[r] = (u >= 0.f && u <= 1.f) ? g2 * diff : 0.f;
-            }
-        }
-        {
-            bf16x8 o;
-#pragma unroll
-            for (int r = 0; r < 8; ++r) o[r] = (bf16_t)v[r];
-            // streaming stores: a kernel's dirty L2 lines are written back at its end, before the next kernel may start
-            // (the XCDs' L2s are not coherent with each other); write-through output leaves nothing to drain (C3 -3.7 %)
-            __builtin_nontemporal_store(o, reinterpret_cast<bf16x8*>(Cb + (size_t)m * p.ldc + n));
-        }
-    }
+    wave_epilogue<ALAY, BLAY, WM>(p, acc, m0 + wm * 64, n0 + wn * 64, z, reinterpret_cast<float*>(smem) + wave * 4096, lane, lsum);
     if (mse) {
         float* red = reinterpret_cast<float*>(smem);
         __syncthreads();                       // every wave is done with its staging tile
@@ -699,9 +746,268 @@ __global__ __launch_bounds__(128 * WM, 2) void gemm_bf16(GemmParams p) {
     GSTAMP(3);
 #endif
 }
+
+// ------------------------------------------------------------------ 256x256 tile, 8 waves of 128x64, 4 phases per K-tile
+// For products whose 256x256 tiling still fills the chip (a layer's dW + dX in one grouped launch: 128 + 128 blocks).
+// Against the 256x128 ring kernel a K-tile moves 2/3 of the DMA bytes and 3/4 of the LDS fragment reads per FLOP, and the
+// two waves of a SIMD never want the matrix pipe at the same time:
+//   * waves as 2 (M) x 4 (N); wave (wr, wc) owns rows wr*128.. (A sub-tile wr) and columns (wc&1)*64.. of B sub-tile
+//     wc>>1 (a sub-tile = 128 x 64 operand elements, 16 KiB, in either orientation: the images of stage_inst / read_frag);
+//   * a K-tile is four PHASES, one 64x32 quadrant of the wave's accumulators each (16 MFMAs = 256 matrix-pipe cycles):
+//       phase 0  reads all of B (8 fragments) + A rows 0..63 (8)   -> quadrant (0,0)      B sub-tiles free after this
+//       phase 1  (no reads)                                         -> quadrant (0,1)
+//       phase 2  reads A rows 64..127 (8)                           -> quadrant (1,1)      A sub-tiles free after this
+//       phase 3  (no reads)                                         -> quadrant (1,0)
+//     a phase = { issue its LDS reads; move one sub-tile of tile t+2 along; barrier; lgkmcnt(0); 16 MFMAs; barrier }.
+//     Waves 4..7 (wr = 1, the SIMD partners of waves 0..3) run ONE BARRIER BEHIND: while one group is in its MFMAs the
+//     other does the memory work (an LDS-DMA piece holds its wave ~100 cycles: issued behind a wave's own MFMAs it
+//     lengthened every phase by that much), then they swap;
+//   * a CU takes LDS-DMA pieces at only ~1 KiB per 38 cycles (~30 B/clk): the 64 pieces of a 256x256x64 K-tile are 1.3 us
+//     against 1.03 us of MFMAs, so this kernel is DMA-bound (measured 1.5 us per K-tile; with the DMA removed 1.03), as is
+//     the 256x128 ring kernel (48 pieces: 0.88 us against 0.55 us of MFMAs) -- per FLOP 1.35x faster here.  Measured
+//     alternatives: every operand piece through registers (buffer_load -> ds_write_b128) saturates the LDS store path
+//     instead (1.7-1.9 us); A by DMA + B through registers spills (1.6 us);
+//   * LDS, all 160 KiB: A sub-tiles in a ring of 3 stages, B sub-tiles in 2.  Phase q of tile t issues sub-tile q of tile
+//     t+2 (A0, A1, B0, B1): the A stage of tile t+2 was last read in phase 2 of tile t-1, the B stage in phase 0 of tile t
+//     -- at least two phases before it is overwritten, so also the trailing group's reads are retired.  ONE counted wait
+//     per K-tile, in phase 3 ahead of its first barrier: the four newest sub-tiles (tile t+2) stay in flight, tile t+1 has
+//     landed; its first read is two barriers later (the trailing group's wait sits one barrier after the leading one's).
+template <int ALAY, int BLAY, int ABL = 0>
+__device__ __forceinline__ void gemm_bf16_256_body(const GemmParams& p, const int bid, const int nblk, char* smem) {
+    constexpr int BM = 256, BNN = 256;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    int tm, tn, z;
+    tile_of_block(p, BM, BNN, bid, nblk, tm, tn, z);
+    if (z >= p.splitk) return;
+    const int m0 = tm * BM, n0 = tn * BNN;
+    const int klen = ((p.K + p.splitk - 1) / p.splitk + BK - 1) / BK * BK;
+    const int kbeg = z * klen;
+    const int kend = min(p.K, kbeg + klen);
+    const int nt = (kend > kbeg) ? (kend - kbeg + BK - 1) / BK : 0;
+    const i32x4 rA = make_rsrc(p.A), rB = make_rsrc(p.B);
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // LDS map: A ring [3][A0, A1] at 0, B ring [2][B0, B1] at 6 * SUB.  sub-tile q of K-tile t: q = 0, 1 -> A0, A1 into A stage
+    // sa; q = 2, 3 -> B0, B1 into B stage t & 1.  2 pieces per wave.
+    // Interior blocks (whole tile inside M x N, K range a multiple of 64) take the FAST form: the lane-dependent part of a
+    // piece's source address is the same for every piece a wave ever issues for an operand (the row-in-piece / chunk
+    // swizzle of stage_inst depends on the lane and, for k-strided images, on the wave's parity only), so it is ONE VGPR
+    // per operand computed here; which piece, which sub-tile and which K-tile only add a wave-uniform byte offset, passed
+    // as the instruction's SGPR soffset.  Both pieces of a sub-tile go out in one asm statement (one M0 save/restore).
+    const bool fast = (m0 + BM <= p.M) && (n0 + BNN <= p.N) && ((kend - kbeg) % BK == 0);
+    unsigned voffA, voffB;
+    {
+        const int w1 = wave & 1;
+        if (ALAY == 0) { const int r = lane >> 3; voffA = (unsigned)(((size_t)(m0 + r) * p.lda + kbeg + 8 * ((lane & 7) ^ (r & 7))) * 2); }
+        else { const int kr = lane >> 4, c = (lane & 15) ^ ((((kr & 3) | (w1 << 2))) << 1); voffA = (unsigned)(((size_t)(kbeg + kr) * p.lda + m0 + 8 * c) * 2); }
+        if (BLAY == 0) { const int r = lane >> 3; voffB = (unsigned)(((size_t)(n0 + r) * p.ldb + kbeg + 8 * ((lane & 7) ^ (r & 7))) * 2); }
+        else { const int kr = lane >> 4, c = (lane & 15) ^ ((((kr & 3) | (w1 << 2))) << 1); voffB = (unsigned)(((size_t)(kbeg + kr) * p.ldb + n0 + 8 * c) * 2); }
+    }
+    // byte offsets (wave-uniform): per piece row-block, per second sub-tile (+128 rows / +128 elements), per K-tile
+    const unsigned pieceA = (ALAY == 0 ? 8u : 4u) * p.lda * 2, pieceB = (BLAY == 0 ? 8u : 4u) * p.ldb * 2;
+    const unsigned subA = ALAY == 0 ? 128u * p.lda * 2 : 256u, subB = BLAY == 0 ? 128u * p.ldb * 2 : 256u;
+    const unsigned tileA = ALAY == 0 ? 128u : 64u * p.lda * 2, tileB = BLAY == 0 ? 128u : 64u * p.ldb * 2;
+    auto dma_pair = [&](i32x4 rsrc, unsigned lds_a, unsigned voff, unsigned soff_a, unsigned soff_b) {
+        if constexpr (ABL & 4) {
+            i32x4 d0, d1;
+            asm volatile("s_nop 3\n\tbuffer_load_dwordx4 %0, %2, %5, %3 offen\n\tbuffer_load_dwordx4 %1, %2, %5, %4 offen"
+                         : "=&v"(d0), "=&v"(d1) : "v"(voff), "s"(soff_a), "s"(soff_b), "s"(rsrc) : "memory");
+            return;
+        }
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 3\n\tbuffer_load_dwordx4 %1, %5, %3 offen lds\n\t"
+                     "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %5, %4 offen lds\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(voff), "s"(lds_a), "s"(soff_a), "s"(soff_b), "s"(rsrc) : "memory");
+    };
+    auto stage_sub = [&](int t, int sa, int q) {
+        if (fast) {
+            const unsigned i0 = wave * 2;
+            if (q < 2) {
+                const unsigned so = (unsigned)t * tileA + (unsigned)q * subA + i0 * pieceA;
+                dma_pair(rA, lds0 + (sa * 2 + q) * SUB + i0 * 1024, voffA, so, so + pieceA);
+            } else {
+                const unsigned so = (unsigned)t * tileB + (unsigned)(q - 2) * subB + i0 * pieceB;
+                dma_pair(rB, lds0 + (6 + (t & 1) * 2 + (q - 2)) * SUB + i0 * 1024, voffB, so, so + pieceB);
+            }
+            return;
+        }
+        const int k0 = kbeg + t * BK;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int inst = wave * 2 + i;
+            if (q < 2) stage_inst<ALAY>(rA, lds0 + (sa * 2 + q) * SUB, p.lda, p.M, m0 + q * 128, k0, kend, inst, lane);
+            else stage_inst<BLAY>(rB, lds0 + (6 + (t & 1) * 2 + (q - 2)) * SUB, p.ldb, p.N, n0 + (q - 2) * 128, k0, kend, inst, lane);
+        }
+    };
+    const bool do_cs = (ALAY == 1) && p.colsum != nullptr && tn == 0;
+    constexpr int CH = BM / 8;
+    float cs8[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) cs8[r] = 0.f;
+    auto colsum_tile = [&](const char* S) {
+        const int c = tid % CH, rg = tid / CH;
+        const char* Ac = S + (c >> 4) * SUB;        // S = this tile's A stage: A0, A1 are adjacent
+        const int cl = c & 15;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int k = rg + 16 * i;
+            const bf16x8 v = *reinterpret_cast<const bf16x8*>(Ac + k * 256 + ((cl ^ (fswz(k) << 1)) << 4));
+#pragma unroll
+            for (int r = 0; r < 8; ++r) cs8[r] += (float)v[r];
+        }
+    };
+
+    // prologue: tiles 0 and 1 (what the phases of "tiles -2, -1" would have issued); start when tile 0 has landed
+    if (nt > 0) { stage_sub(0, 0, 0); stage_sub(0, 0, 1); stage_sub(0, 0, 2); stage_sub(0, 0, 3); }
+    if (nt > 1) { stage_sub(1, 1, 0); stage_sub(1, 1, 1); stage_sub(1, 1, 2); stage_sub(1, 1, 3); }
+    if (nt > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");     // tile 0 has landed; tile 1 is retired by the wait of phase 3
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier();          // waves 4..7 run one barrier behind from here on
+
+    bf16x8 fa[2][4], fb[2][4];                          // [k-step][fragment]: A half (64 rows), all 64 B columns
+    int sa = 0;                                         // A ring stage of tile t; tile t+2 goes to stage sa + 2 (mod 3)
+    for (int t = 0; t < nt; ++t) {
+        const char* As = smem + (sa * 2 + wr) * SUB;
+        const char* Bs = smem + (6 + (t & 1) * 2 + (wc >> 1)) * SUB;
+        const int bx = (wc & 1) * 64;
+        int sa2 = sa + 2; if (sa2 >= 3) sa2 -= 3;
+#pragma unroll
+        for (int ph = 0; ph < 4; ++ph) {
+            // ---- this phase's LDS reads
+            if (ph == 0 && !((ABL & 2) && t > 0)) {
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) fb[ks][j] = read_frag<BLAY>(Bs, bx + 16 * j, ks, lane);
+            }
+            if ((ph == 0 || ph == 2) && !((ABL & 2) && t > 0)) {
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) fa[ks][i] = read_frag<ALAY>(As, (ph >> 1) * 64 + 16 * i, ks, lane);
+            }
+            if (ALAY == 1 && do_cs && ph == 1) colsum_tile(smem + sa * 2 * SUB);
+            // ---- this phase's DMA: sub-tile ph of tile t+2
+            if (t + 2 < nt && !(ABL & 1)) stage_sub(t + 2, sa2, ph);
+            if (ph == 3) {
+                if (t + 2 < nt) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");       // tile t+2 (8 pieces per wave) stays in flight
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_s_barrier();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
+            {
+                const int ia = (ph >> 1) * 4;                        // accumulator rows: phases 0, 1 -> 0..3; phases 2, 3 -> 4..7
+                const int jb = (ph == 1 || ph == 2) ? 2 : 0;         // B columns 32..63 in phases 1, 2; 0..31 in phases 0, 3
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+                            acc[ia + i][jb + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[ks][jb + j], fa[ks][i], acc[ia + i][jb + j], 0, 0, 0);
+            }
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_s_barrier();
+        }
+        sa = sa + 1; if (sa == 3) sa = 0;
+    }
+    if (wr == 0) __builtin_amdgcn_s_barrier();          // the leading group meets the trailing group's last barrier
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    if (ALAY == 1 && do_cs) {
+        float* red = reinterpret_cast<float*>(smem);           // [16 row groups][BM]
+        const int c = tid % CH, rg = tid / CH;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) red[rg * BM + 8 * c + r] = cs8[r];
+        __syncthreads();
+        if (tid < BM && m0 + tid < p.M) {
+            float a = 0.f;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) a += red[g * BM + tid];
+            p.colsum[(size_t)z * p.colsum_stride + m0 + tid] = a;
+        }
+        __syncthreads();
+    }
+    // two passes of the 64x64 wave epilogue: accumulator rows 0..3 (tile rows wr*128 .. +63), then 4..7
+    float lsum = 0.f;
+    float* Wt = reinterpret_cast<float*>(smem) + wave * 4096;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        f32x4 part[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) part[i][j] = acc[4 * h + i][j];
+        wave_epilogue<ALAY, BLAY, 4>(p, part, m0 + wr * 128 + h * 64, n0 + wc * 64, z, Wt, lane, lsum);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the wave's own LDS reads of pass 0 are done before pass 1 overwrites Wt
+    }
+}
+
+template <int ALAY, int BLAY, int WM, int ABL = 0>
+__global__ __launch_bounds__(128 * WM, 2) void gemm_bf16(GemmParams p) {
+    __shared__ __attribute__((aligned(16))) char smem[RingGeom<WM>::LDS_BYTES];
+    gemm_bf16_body<ALAY, BLAY, WM, ABL>(p, blockIdx.x, gridDim.x, smem);
+}
+
+// Several independent products in ONE launch (a layer's weight gradient and input gradient both consume the same dy):
+// blocks [blk0[i], blk0[i+1]) work on product i.  The long-running products are listed first (the dispatcher hands out
+// blocks in order, so a CU that drew a split-K weight-gradient block of 2x the K-tiles is balanced by one that draws two
+// input-gradient blocks), and nothing waits for a device-wide kernel boundary in between: a CU's next block starts while
+// other CUs are still in their epilogues.  Products with a fused loss epilogue cannot be grouped (its arrival counter
+// counts the blocks of ONE launch).
+struct GemmGroup { int n; int blk0[5]; GemmParams p[4]; };
+__global__ __launch_bounds__(512, 2) void gemm_bf16_group(GemmGroup g) {
+    __shared__ __attribute__((aligned(16))) char smem[RingGeom<4>::LDS_BYTES];
+    const int b = blockIdx.x;
+    int i = 0;
+    while (i + 1 < g.n && b >= g.blk0[i + 1]) ++i;
+    const GemmParams& p = g.p[i];
+    const int bid = b - g.blk0[i], nblk = g.blk0[i + 1] - g.blk0[i];
+    const int lay = ((p.flags & AFR_GEMM_A_KSTRIDED) ? 2 : 0) | ((p.flags & AFR_GEMM_B_KSTRIDED) ? 1 : 0);
+    if (lay == 3) gemm_bf16_body<1, 1, 4>(p, bid, nblk, smem);
+    else if (lay == 1) gemm_bf16_body<0, 1, 4>(p, bid, nblk, smem);
+    else if (lay == 0) gemm_bf16_body<0, 0, 4>(p, bid, nblk, smem);
+    else gemm_bf16_body<1, 0, 4>(p, bid, nblk, smem);
+}
+__global__ __launch_bounds__(512, 2) void gemm_bf16_group256(GemmGroup g) {
+    __shared__ __attribute__((aligned(16))) char smem[10 * SUB];   // all 160 KiB: A ring 3 x 32 KiB + B ring 2 x 32 KiB
+    const int b = blockIdx.x;
+    int i = 0;
+    while (i + 1 < g.n && b >= g.blk0[i + 1]) ++i;
+    const GemmParams& p = g.p[i];
+    const int bid = b - g.blk0[i], nblk = g.blk0[i + 1] - g.blk0[i];
+    const int lay = ((p.flags & AFR_GEMM_A_KSTRIDED) ? 2 : 0) | ((p.flags & AFR_GEMM_B_KSTRIDED) ? 1 : 0);
+    if (lay == 3) gemm_bf16_256_body<1, 1>(p, bid, nblk, smem);
+    else if (lay == 1) gemm_bf16_256_body<0, 1>(p, bid, nblk, smem);
+    else if (lay == 0) gemm_bf16_256_body<0, 0>(p, bid, nblk, smem);
+    else gemm_bf16_256_body<1, 0>(p, bid, nblk, smem);
+}
+#ifdef AFR_GEMM_LAB
+template <int ABL>
+__global__ __launch_bounds__(512, 2) void gemm_bf16_lab256(GemmGroup g) {
+    __shared__ __attribute__((aligned(16))) char smem[10 * SUB];
+    gemm_bf16_256_body<0, 0, ABL>(g.p[0], blockIdx.x, gridDim.x, smem);
+}
+#endif
 }  // namespace bf16k
 
 // ---------------------------------------------------------------------------------------- launch
+#ifdef AFR_GEMM_LAB
+static int g_gemm_variant = getenv("AFR_GEMM_VARIANT") ? atoi(getenv("AFR_GEMM_VARIANT")) : 0;
+extern "C" void afr_dbg_set_gemm_variant(int v) { g_gemm_variant = v; }
+#endif
 #ifdef AFR_GEMM_TIMING
 extern "C" int afr_dbg_gemm_stamps(void* devbuf) {
     return (int)hipMemcpyToSymbol(HIP_SYMBOL(bf16k::g_gemm_stamps), &devbuf, sizeof(void*));
@@ -726,6 +1032,51 @@ const char* afr_gemm_kernel_name(int dtype, const GemmParams& p) {
     if (dtype != AFR_BF16) return f32n[a][b];
     return bfn[a][b][bf16_use_wide(p) ? 1 : 0];
 }
+// true when the product would run on the 256x128 ring kernel by itself (what a grouped launch is built from)
+bool afr_gemm_groupable(int dtype, const GemmParams& p) {
+    return dtype == AFR_BF16 && p.M > 0 && p.N > 0 && !p.mse_target && !p.ad_p && p.K / p.splitk >= 256;
+}
+// How a layer's gradient pair (dX: B x K_in over N_out; dW: N_out x K_in over the batch) is launched: with 256x256 tiles
+// when those fill most of the chip in ONE round (dW split so that its blocks run as many K-tiles as dX's), else with
+// 256x128 tiles and dW blocks of twice the K-tiles (a CU draws one long block or two short ones).
+void afr_gemm_pair_plan(int B, int n_out, int k_in, int* tile256, int* splitk) {
+    const long long dx256 = (long long)((B + 255) / 256) * ((k_in + 255) / 256);
+    const long long dw256 = (long long)((n_out + 255) / 256) * ((k_in + 255) / 256);
+    int sk = n_out > 0 ? (B + n_out - 1) / n_out : 1;                 // dW K-tiles per block == dX K-tiles per block
+    if (sk < 1) sk = 1;
+    const long long total = dx256 + dw256 * sk;
+    const char* force = getenv("AFR_GEMM_PAIR_TILE");                  // 128 | 256: kernel A/B measurements
+    bool use256 = total >= 192 && total <= 272 && B / sk >= 256;
+    if (force) use256 = atoi(force) == 256;
+    if (use256) { *tile256 = 1; *splitk = sk; return; }
+    *tile256 = 0;
+    sk = n_out > 0 ? (B + 2 * n_out - 1) / (2 * n_out) : 1;
+    if (sk < 1) sk = 1;
+    if (B / sk < 256) sk = 0;                                         // 0: no grouped launch
+    *splitk = sk;
+}
+hipError_t afr_launch_gemm_group(int dtype, const GemmParams* ps, int n, int tile256, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    bool ok = n <= 4;
+    for (int i = 0; i < n && ok; ++i) ok = afr_gemm_groupable(dtype, ps[i]);
+    if (!ok || n == 1) {
+        for (int i = 0; i < n; ++i) { hipError_t e = afr_launch_gemm(dtype, ps[i], s); if (e != hipSuccess) return e; }
+        return hipSuccess;
+    }
+    bf16k::GemmGroup g;
+    g.n = n;
+    int total = 0;
+    for (int i = 0; i < n; ++i) {
+        g.p[i] = ps[i];
+        g.blk0[i] = total;
+        int nb = ((ps[i].M + 255) / 256) * ((ps[i].N + (tile256 ? 255 : 127)) / (tile256 ? 256 : 128)) * ps[i].splitk;
+        total += (nb + 7) & ~7;        // each product's range starts on a multiple of 8: blocks b, b+8, ... keep sharing an XCD
+    }
+    g.blk0[n] = total;
+    if (tile256) hipLaunchKernelGGL(bf16k::gemm_bf16_group256, dim3(total), dim3(512), 0, s, g);
+    else hipLaunchKernelGGL(bf16k::gemm_bf16_group, dim3(total), dim3(512), 0, s, g);
+    return hipGetLastError();
+}
 hipError_t afr_launch_gemm(int dtype, const GemmParams& p, hipStream_t s) {
     const int a = (p.flags & AFR_GEMM_A_KSTRIDED) ? 1 : 0, b = (p.flags & AFR_GEMM_B_KSTRIDED) ? 1 : 0;
     if (p.M <= 0 || p.N <= 0) return hipSuccess;
@@ -736,6 +1087,43 @@ hipError_t afr_launch_gemm(int dtype, const GemmParams& p, hipStream_t s) {
         dim3 grid(tiles * p.splitk, 1, 1);
 #define LB(AL, BL) do { if (wide) hipLaunchKernelGGL((bf16k::gemm_bf16<AL, BL, 4>), grid, dim3(512), 0, s, p); \
                         else hipLaunchKernelGGL((bf16k::gemm_bf16<AL, BL, 2>), grid, dim3(256), 0, s, p); } while (0)
+#ifdef AFR_GEMM_LAB
+        if (g_gemm_variant == 260 && !a && !b) {
+            bf16k::GemmGroup g;
+            g.n = 1; g.p[0] = p; g.blk0[0] = 0;
+            g.blk0[1] = ((((p.M + 255) / 256) * ((p.N + 255) / 256) * p.splitk) + 7) & ~7;
+            hipLaunchKernelGGL((bf16k::gemm_bf16_lab256<6>), dim3(g.blk0[1]), dim3(512), 0, s, g);
+            return hipGetLastError();
+        }
+        if (g_gemm_variant >= 257 && g_gemm_variant <= 259 && !a && !b) {
+            bf16k::GemmGroup g;
+            g.n = 1; g.p[0] = p; g.blk0[0] = 0;
+            g.blk0[1] = ((((p.M + 255) / 256) * ((p.N + 255) / 256) * p.splitk) + 7) & ~7;
+            if (g_gemm_variant == 257) hipLaunchKernelGGL((bf16k::gemm_bf16_lab256<1>), dim3(g.blk0[1]), dim3(512), 0, s, g);
+            else if (g_gemm_variant == 258) hipLaunchKernelGGL((bf16k::gemm_bf16_lab256<2>), dim3(g.blk0[1]), dim3(512), 0, s, g);
+            else hipLaunchKernelGGL((bf16k::gemm_bf16_lab256<3>), dim3(g.blk0[1]), dim3(512), 0, s, g);
+            return hipGetLastError();
+        }
+        if (g_gemm_variant == 256 || g_gemm_variant == 128) {       // one product through the grouped kernels
+            bf16k::GemmGroup g;
+            g.n = 1; g.p[0] = p; g.blk0[0] = 0;
+            const int t256 = g_gemm_variant == 256;
+            const int nb = ((p.M + 255) / 256) * ((p.N + (t256 ? 255 : 127)) / (t256 ? 256 : 128)) * p.splitk;
+            g.blk0[1] = (nb + 7) & ~7;
+            if (t256) hipLaunchKernelGGL(bf16k::gemm_bf16_group256, dim3(g.blk0[1]), dim3(512), 0, s, g);
+            else hipLaunchKernelGGL(bf16k::gemm_bf16_group, dim3(g.blk0[1]), dim3(512), 0, s, g);
+            return hipGetLastError();
+        }
+        if (wide && !a && !b && g_gemm_variant >= 100 && g_gemm_variant < 116) {
+            switch (g_gemm_variant - 100) {
+#define LABL(x) case x: hipLaunchKernelGGL((bf16k::gemm_bf16<0, 0, 4, x>), grid, dim3(512), 0, s, p); break;
+                LABL(1) LABL(2) LABL(3) LABL(8)
+#undef LABL
+                default: hipLaunchKernelGGL((bf16k::gemm_bf16<0, 0, 4, 0>), grid, dim3(512), 0, s, p);
+            }
+            return hipGetLastError();
+        }
+#endif
         if (!a && !b) LB(0, 0);
         else if (!a && b) LB(0, 1);
         else if (a && !b) LB(1, 0);

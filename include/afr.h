@@ -57,7 +57,8 @@ typedef struct afr_config {
     int32_t rank;        /* data-parallel rank: gives each replica its own dropout stream         */
     int32_t reserved;    /* bit 0: keep the optimizer un-fused in afr_train_step (gradients of every tensor are
                             then materialised; otherwise the sheet model's fc_output.weight is updated inside its
-                            weight-gradient GEMM and its gradient never reaches HBM)                              */
+                            weight-gradient GEMM and its gradient never reaches HBM)
+                            bit 1: one launch per product in backward (no grouped dW+dX launches): A/B measurements   */
 } afr_config;
 
 typedef struct afr_plan afr_plan;
