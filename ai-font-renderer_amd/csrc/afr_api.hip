@@ -79,6 +79,10 @@ struct afr_plan {
     size_t o_table = 0;            // glyph: [Emb; Font] . W1^T, the first Linear folded through the tables
     size_t o_dw1 = 0;              // glyph: compact dW1 [N1][E] extracted from the widened weight-gradient slabs
     int k0 = 0;                    // glyph: columns of h0' = [h0 | one-hot] when the first layer is folded, else 0
+    // glyph, one small hidden layer (BASELINE C1 / C2): the whole step as ONE fused kernel + the grouped reduce (glyph_fused.hip)
+    bool fused1 = false;
+    bool wT_valid = false;         // bf16: the transposed operand copies W1T / W2T match the current parameters
+    size_t o_w1t = 0, o_w2t = 0, o_slab1 = 0;
     // glyph layer table
     struct Layer { int N, K; int64_t w_off, b_off; int sk = 1; size_t o_slab_w = 0, o_slab_b = 0; };
     std::vector<Layer> layers;
@@ -244,6 +248,17 @@ extern "C" int afr_plan_create(const afr_config* c, afr_plan** out) {
             p->o_dw1 = carve((size_t)c->hidden[0] * E * sizeof(float));
         }
         p->o_slab_e = carve(eb * (size_t)(c->vocab + c->n_fonts) * E * sizeof(float));
+        if (c->n_hidden == 1 && afr_glyph1_eligible(E, c->hidden[0], Pix, c->vocab, c->n_fonts) &&
+            afr_glyph1_lds_bytes(c->dtype, E, c->hidden[0], Pix, c->vocab + c->n_fonts) <= 160 * 1024) {
+            p->fused1 = true;
+            const size_t nblk = (B + afr_glyph1_rows(c->dtype) - 1) / afr_glyph1_rows(c->dtype);
+            p->o_slab1 = carve(nblk * (size_t)p->total * sizeof(float));
+            p->o_loss = carve((1040 + nblk + 64) * sizeof(float));           // room for one loss partial per block
+            if (c->dtype == AFR_BF16) {
+                p->o_w1t = carve((size_t)c->hidden[0] * E * 2);
+                p->o_w2t = carve((size_t)Pix * c->hidden[0] * 2);
+            }
+        }
     } else {
         delete p;
         return fail(AFR_EINVAL, "unknown model kind %d", c->kind);
@@ -302,6 +317,7 @@ extern "C" int afr_bind(afr_plan* p, float* params, float* grads, float* m, floa
     p->P = params; p->G = grads; p->M = m; p->V = v;
     p->ws = (char*)ws; p->ws_bytes = ws_bytes;
     p->have_du = false;
+    p->wT_valid = false;
     return AFR_OK;
 }
 
@@ -524,6 +540,7 @@ static int run_reduce_group(afr_plan* p, hipStream_t s, const RTable& rt) {
 extern "C" int afr_sync_params(afr_plan* p, void* stream) {
     if (!p || !p->P) return fail(AFR_ESTATE, "plan has no bound parameters");
     DevGuard dg(p->device);
+    p->wT_valid = false;
     if (p->cfg.dtype != AFR_BF16) return AFR_OK;
     HIPCHK(afr_launch_f32_to_bf16(p->P, (bf16_t*)(p->ws + p->o_shadow), p->total, (hipStream_t)stream));
     return AFR_OK;
@@ -828,6 +845,7 @@ extern "C" int afr_adamw_step(afr_plan* p, float lr, float b1, float b2, float e
     bf16_t* shadow = p->cfg.dtype == AFR_BF16 ? (bf16_t*)(p->ws + p->o_shadow) : nullptr;
     ProfScope ps(p, s, "adamw", 0.0, (double)p->total * (shadow ? 30.0 : 28.0));
     HIPCHK(afr_launch_adamw(p->P, p->G, p->M, p->V, shadow, p->total, lr, b1, b2, eps, wd, bc1, bc2, gscale, s));
+    p->wT_valid = false;
     return AFR_OK;
 }
 
@@ -842,6 +860,7 @@ static int reduce_and_step(afr_plan* p, hipStream_t s, RTable& rt, float lr, flo
     rt.adam = 1; rt.ad_decay = 1.f - lr * wd; rt.ad_b1 = b1; rt.ad_b2 = b2; rt.ad_eps = eps; rt.ad_step = lr / bc1;
     rt.ad_rsqrt_bc2 = (float)(1.0 / std::sqrt((double)bc2));
     rt.gbase = p->G; rt.P = p->P; rt.M = p->M; rt.V = p->V; rt.shadow = shadow;
+    p->wT_valid = false;
     int rc = run_reduce_group(p, s, rt);
     if (rc) return rc;
     for (const Tensor& tn : p->params) {
@@ -904,6 +923,57 @@ static int sheet_fused_step(afr_plan* p, hipStream_t s, float lr, float b1, floa
     return AFR_OK;
 }
 
+// One fused launch for the whole forward + loss + backward of a small one-hidden-layer glyph net (glyph_fused.hip); the
+// per-block partial gradients it leaves are registered in `rt` for the grouped reduce (with or without AdamW).
+static int glyph1_fused(afr_plan* p, const int64_t* x, const int64_t* font, const void* target, int tdtype, int B,
+                        int64_t mean_elems, float* loss_accum, hipStream_t s, RTable& rt) {
+    const afr_config& c = p->cfg;
+    if (!x) return fail(AFR_EINVAL, "x is null");
+    if (B <= 0 || B > c.max_batch) return fail(AFR_EINVAL, "batch %d outside 1..max_batch=%d", B, c.max_batch);
+    if (c.n_fonts > 0 && !font) return fail(AFR_EINVAL, "font ids are required when n_fonts > 0");
+    const auto& l1 = p->layers[0];
+    const auto& l2 = p->layers[1];
+    const int E = c.embed_dim, N1 = l1.N, Pix = l2.N;
+    const bool b16 = c.dtype == AFR_BF16;
+    if (b16 && !p->wT_valid) {
+        ProfScope ps(p, s, "glyph1_transpose", 0.0, 0.0);
+        HIPCHK(afr_launch_transpose_bf16(p->P + l1.w_off, (bf16_t*)(p->ws + p->o_w1t), N1, E, s));
+        HIPCHK(afr_launch_transpose_bf16(p->P + l2.w_off, (bf16_t*)(p->ws + p->o_w2t), Pix, N1, s));
+        p->wT_valid = true;
+    }
+    Glyph1Args a;
+    a.x = x; a.font = font; a.target = target; a.tdtype = tdtype;
+    a.B = B; a.E = E; a.N1 = N1; a.P = Pix; a.vocab = c.vocab; a.n_fonts = c.n_fonts;
+    a.emb = p->P + p->emb_off; a.femb = c.n_fonts > 0 ? p->P + p->font_off : nullptr;
+    a.b1 = p->P + l1.b_off; a.b2 = p->P + l2.b_off;
+    a.W1 = weight_ptr(p, l1.w_off); a.W2 = weight_ptr(p, l2.w_off);
+    a.W1T = b16 ? (const void*)(p->ws + p->o_w1t) : (const void*)(p->P + l1.w_off);
+    a.W2T = b16 ? (const void*)(p->ws + p->o_w2t) : (const void*)(p->P + l2.w_off);
+    a.slabs = (float*)(p->ws + p->o_slab1); a.slab_stride = p->total;
+    a.o_emb = p->emb_off; a.o_font = c.n_fonts > 0 ? p->font_off : 0; a.o_w1 = l1.w_off; a.o_b1 = l1.b_off; a.o_w2 = l2.w_off; a.o_b2 = l2.b_off;
+    float* scratch = (float*)(p->ws + p->o_loss);
+    a.inv_n = (float)(1.0 / (double)mean_elems); a.loss_partial = scratch + 1040; a.counter = reinterpret_cast<unsigned*>(scratch + 1032);
+    a.loss_accum = loss_accum; a.err = (uint32_t*)(p->ws + p->o_err);
+    const int R = afr_glyph1_rows(c.dtype), nblk = (B + R - 1) / R;
+    {
+        const double fl = 6.0 * B * ((double)E * N1 + (double)N1 * Pix);
+        ProfScope ps(p, s, b16 ? "glyph1_step<bf16>" : "glyph1_step<f32>", fl, (double)nblk * p->total * 4.0 + (double)B * Pix);
+        HIPCHK(afr_launch_glyph1_step(c.dtype, a, s));
+    }
+    for (const Tensor& tn : p->params) {
+        afr_rtable_add(rt, p->G + tn.off, a.slabs + tn.off, nblk, p->total, (tn.numel + 3) / 4 * 4);
+        // when the optimizer runs inside this reduce, it also keeps the transposed operand copies current
+        if (b16 && rt.nseg > 0 && !rt.overflow) {
+            RSeg& sg = rt.seg[rt.nseg - 1];
+            if (tn.off == l1.w_off) { sg.shT = (bf16_t*)(p->ws + p->o_w1t); sg.tN = N1; sg.tK = E; }
+            if (tn.off == l2.w_off) { sg.shT = (bf16_t*)(p->ws + p->o_w2t); sg.tN = Pix; sg.tK = N1; }
+        }
+    }
+    p->last_x = x; p->last_font = font; p->last_B = B; p->last_L = 1; p->last_training = 1;
+    p->have_du = false; p->next_stage = 0;
+    return AFR_OK;
+}
+
 extern "C" int afr_forward_loss(afr_plan* p, const int64_t* x, const int64_t* font, const void* target, int tdtype, int B, int L,
                                 int64_t mean_elems, float* loss_accum, uint64_t step, void* stream) {
     if (!target || !loss_accum) return fail(AFR_EINVAL, "target and loss_accum are required");
@@ -922,6 +992,21 @@ extern "C" int afr_train_step(afr_plan* p, const int64_t* x, const int64_t* font
     if (mean_elems <= 0) return fail(AFR_EINVAL, "mean_elems must be positive");
     if (!p || !p->P) return fail(AFR_ESTATE, "plan has no bound parameters");
     DevGuard dg(p->device);
+    if (p->fused1 && !(p->cfg.reserved & 4)) {
+        // small glyph net: forward + loss + backward in ONE launch, then the grouped reduce (with AdamW when stepping here)
+        if (!p->G) return fail(AFR_ESTATE, "plan has no bound gradient buffer");
+        RTable rt;
+        if ((rc = glyph1_fused(p, x, font, target, tdtype, B, mean_elems, loss_accum, (hipStream_t)stream, rt))) return rc;
+        if (do_step && p->M && p->V && !(p->cfg.reserved & 1)) {
+            if (t < 1) return fail(AFR_EINVAL, "t starts at 1");
+            rc = reduce_and_step(p, (hipStream_t)stream, rt, lr, b1, b2, eps, wd, t);
+            p->wT_valid = rc == AFR_OK;                 // the reduce's AdamW wrote W1T / W2T beside the shadow
+            return rc;
+        }
+        if ((rc = run_reduce_group(p, (hipStream_t)stream, rt))) return rc;
+        if (do_step && (rc = afr_adamw_step(p, lr, b1, b2, eps, wd, t, 1.f, stream))) return rc;
+        return AFR_OK;
+    }
     // the loss and its gradient are computed in the epilogue of the last forward GEMM: u never touches HBM
     FusedLoss fl{target, tdtype, mean_elems, loss_accum};
     if ((rc = forward_impl(p, x, font, B, L, nullptr, 1, step, stream, &fl))) return rc;

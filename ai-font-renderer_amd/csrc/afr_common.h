@@ -133,7 +133,11 @@ const char* afr_gemm_kernel_name(int dtype, const GemmParams& p);
 hipError_t afr_launch_reduce(float* dst, const float* slabs, int nslabs, long long slab_stride, long long n,
                              float scale, int accumulate, hipStream_t s);
 // grouped reduction: every gradient tensor that was produced as partial slabs, in ONE launch
-struct RSeg { float* dst; const float* src; long long stride; long long n4; int nslabs; int blk0; int nblk; int deep; };
+struct RSeg {
+    float* dst; const float* src; long long stride; long long n4; int nslabs; int blk0; int nblk; int deep;
+    // optional (with the fused optimizer): a TRANSPOSED bf16 copy of this [tN][tK] weight, shT[k][n], kept current too
+    bf16_t* shT = nullptr; int tN = 0, tK = 0;
+};
 // every gradient tensor of the deepest glyph net (AFR_MAX_HIDDEN + 1 Linears: weight + bias each) plus the folded first
 // layer's extra segments (compact dW1, embedding and font partials) fits; afr_api.hip static_asserts it
 constexpr int AFR_RT_MAXSEG = 24;
@@ -198,3 +202,20 @@ hipError_t afr_launch_sheet_fwd(int act_dtype, const SheetDims& d, const SheetPa
 hipError_t afr_launch_sheet_bwd(int act_dtype, const SheetDims& d, const SheetParams& P, const SheetDrop& dr,
                                 const int64_t* x, int ldx, int B, const void* dz, float ln_eps, float* slabs,
                                 const SheetSlabOff& so, hipStream_t s);
+
+// fused step of the small one-hidden-layer glyph nets (glyph_fused.hip)
+struct Glyph1Args {
+    const int64_t* x; const int64_t* font; const void* target; int tdtype;
+    int B, E, N1, P, vocab, n_fonts;
+    const float *emb, *femb, *b1, *b2;       // f32 masters
+    const void *W1, *W2;                     // [N1][E], [P][N1] in the operand type (f32 masters / bf16 shadow)
+    const void *W1T, *W2T;                   // bf16 mode: [E][N1], [N1][P]; f32 mode: the f32 masters again (gathered)
+    float* slabs; long long slab_stride;     // slab b: this block's partial gradients, flat-buffer layout
+    long long o_emb, o_font, o_w1, o_b1, o_w2, o_b2;
+    float inv_n; float* loss_partial; unsigned* counter; float* loss_accum; uint32_t* err;
+};
+int afr_glyph1_rows(int dtype);
+bool afr_glyph1_eligible(int E, int N1, int P, int vocab, int n_fonts);
+size_t afr_glyph1_lds_bytes(int dtype, int E, int N1, int P, int table_rows);
+hipError_t afr_launch_transpose_bf16(const float* W, bf16_t* WT, int N, int K, hipStream_t s);
+hipError_t afr_launch_glyph1_step(int dtype, const Glyph1Args& a, hipStream_t s);

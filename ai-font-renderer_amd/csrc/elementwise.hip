@@ -84,6 +84,13 @@ __device__ __forceinline__ void reduce_finish(const RTable& t, const RSeg& sg, l
             bf16x4 o = {(bf16_t)pp.x, (bf16_t)pp.y, (bf16_t)pp.z, (bf16_t)pp.w};
             *reinterpret_cast<bf16x4*>(t.shadow + off) = o;
         }
+        if (sg.shT) {                      // 4 consecutive k of one row n (tK is a multiple of 4)
+            const int n = (int)((4 * i) / sg.tK), k = (int)(4 * i - (long long)n * sg.tK);
+            sg.shT[(size_t)k * sg.tN + n] = (bf16_t)pp.x;
+            sg.shT[(size_t)(k + 1) * sg.tN + n] = (bf16_t)pp.y;
+            sg.shT[(size_t)(k + 2) * sg.tN + n] = (bf16_t)pp.z;
+            sg.shT[(size_t)(k + 3) * sg.tN + n] = (bf16_t)pp.w;
+        }
     } else {
         reinterpret_cast<float4*>(sg.dst)[i] = a;
     }
@@ -136,6 +143,7 @@ void afr_rtable_add(RTable& t, float* dst, const float* src, int nslabs, long lo
     if (t.nseg >= AFR_RT_MAXSEG) { t.overflow = 1; return; }     // the launch refuses an overflowed table: never a silent drop
     RSeg& sg = t.seg[t.nseg];
     sg.dst = dst; sg.src = src; sg.stride = stride; sg.n4 = n / 4; sg.nslabs = nslabs; sg.blk0 = t.nblocks;
+    sg.shT = nullptr; sg.tN = sg.tK = 0;
     sg.deep = nslabs >= 32;
     const int cols = sg.deep ? 64 : 256;
     long long nb = (sg.n4 + cols - 1) / cols;       // one float4 per thread where possible: measured 2x faster than

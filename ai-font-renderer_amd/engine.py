@@ -25,8 +25,9 @@ def _stream(device=None):
     return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
-def make_afr_config(cfg, dtype, max_batch, seed=42, rank=0):
+def make_afr_config(cfg, dtype, max_batch, seed=42, rank=0, flags=0):
     c = _lib.AfrConfig()
+    c.reserved = int(flags)          # include/afr.h: bit 0 un-fused optimizer, bit 1 no grouped GEMM launches, bit 2 no fused small-net step
     c.dtype = _DT[dtype]
     c.max_batch = int(max_batch)
     c.vocab = cfg.vocab
@@ -54,12 +55,12 @@ class Engine:
     """One plan + its device buffers.  `params[name]` are views into the flat float32 buffer in
     state_dict order, so checkpoints interchange with the reference (helpers.py:76-105)."""
 
-    def __init__(self, cfg, dtype="f32", max_batch=1024, device=None, seed=42, rank=0, with_optimizer=True):
+    def __init__(self, cfg, dtype="f32", max_batch=1024, device=None, seed=42, rank=0, with_optimizer=True, flags=0):
         if not torch.cuda.is_available():
             raise RuntimeError("ai_font_renderer_amd.Engine needs an MI355X: the hot path has no CPU fallback")
         self.lib = _lib.lib()
         self.cfg, self.dtype, self.max_batch = cfg, dtype, int(max_batch)
-        self.seed, self.rank = int(seed), int(rank)
+        self.seed, self.rank, self.flags = int(seed), int(rank), int(flags)
         self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
         self._plan = None
         self._make_plan(self.max_batch)
@@ -95,7 +96,7 @@ class Engine:
         if self._plan:
             self.lib.afr_plan_destroy(self._plan)
         self.max_batch = int(max_batch)
-        self._c = make_afr_config(self.cfg, self.dtype, self.max_batch, self.seed, self.rank)
+        self._c = make_afr_config(self.cfg, self.dtype, self.max_batch, self.seed, self.rank, self.flags)
         self._plan = C.c_void_p()
         _lib.check(self.lib.afr_plan_create(C.byref(self._c), C.byref(self._plan)))
 

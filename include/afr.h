@@ -58,7 +58,9 @@ typedef struct afr_config {
     int32_t reserved;    /* bit 0: keep the optimizer un-fused in afr_train_step (gradients of every tensor are
                             then materialised; otherwise the sheet model's fc_output.weight is updated inside its
                             weight-gradient GEMM and its gradient never reaches HBM)
-                            bit 1: one launch per product in backward (no grouped dW+dX launches): A/B measurements   */
+                            bit 1: one launch per product in backward (no grouped dW+dX launches): A/B measurements
+                            bit 2: small one-hidden-layer glyph nets through the generic per-layer kernels instead of
+                            the fused whole-step kernel of afr_train_step (A/B measurements, parity cross-checks)         */
 } afr_config;
 
 typedef struct afr_plan afr_plan;

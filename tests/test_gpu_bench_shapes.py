@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 import torch
 
-from .util import GlyphConfig, engine_rounding, glyph_inputs, maxabs, oracle, rnd_du, synth, tparams
+from .util import GlyphConfig, engine_rounding, fused1_eligible, glyph_inputs, maxabs, oracle, rnd_du, synth, tparams
 
 pytestmark = pytest.mark.gpu
 
@@ -62,7 +62,8 @@ def _oracle_step_with_engine_masks(cfg, dtype, eng, x, font, tu8):
     return P, float(lref), oracle.glyph_backward(P, cache, rnd_du(rnd, du), cfg, rnd=rnd), u_eng
 
 
-@pytest.mark.parametrize("workload,dtype,tol", [("c3", "bf16", 3e-2), ("c2", "bf16", 3e-2), ("c3", "f32", 1e-4)])
+@pytest.mark.parametrize("workload,dtype,tol", [("c3", "bf16", 3e-2), ("c2", "bf16", 3e-2), ("c3", "f32", 1e-4), ("c2", "f32", 1e-4),
+                                                ("c1", "f32", 1e-4), ("c1", "bf16", 3e-2)])
 def test_benchmarked_batch_full_step_vs_oracle(workload, dtype, tol):
     """BASELINE configs[2] (C3: 8192 glyphs, 1024-wide, font ids) and configs[1] (C2: 4096 glyphs, hidden 256) exactly as
     bench.py runs them: afr_train_step with the loss fused into the last GEMM's epilogue, split-K weight-gradient GEMMs
@@ -73,7 +74,17 @@ def test_benchmarked_batch_full_step_vs_oracle(workload, dtype, tol):
     x, font, tu8 = glyph_inputs(cfg, B)
     xt, ft, tt = torch.from_numpy(x), torch.from_numpy(font) if cfg.n_fonts else None, torch.from_numpy(tu8)
     eng = _engine(cfg, dtype=dtype, max_batch=B)
-    P, lref, Gref, _ = _oracle_step_with_engine_masks(cfg, dtype, eng, x, font, tu8)
+    if fused1_eligible(cfg):
+        # afr_train_step runs this net as ONE fused kernel: no activation ever leaves LDS, so there are no engine masks to
+        # read back.  Both sides round at the same points (util.engine_rounding), so their masks differ only where an
+        # accumulation-order difference crosses a threshold: rare enough for the tolerance.
+        rnd = engine_rounding(cfg, dtype, train_step=True)
+        P = tparams(cfg)
+        _, cache = oracle.glyph_forward(P, xt, torch.from_numpy(font), cfg, rnd=rnd)
+        lref, du = oracle.mse_loss_grad(cache["u"], torch.from_numpy(tu8.astype(np.float32) / 255.0))
+        lref, Gref = float(lref), oracle.glyph_backward(P, cache, rnd_du(rnd, du), cfg, rnd=rnd)
+    else:
+        P, lref, Gref, _ = _oracle_step_with_engine_masks(cfg, dtype, eng, x, font, tu8)
     eng.read_loss()
     eng.train_step(xt, tt, font=ft, do_step=False)              # the bench's kernels, gradients materialised
     assert abs(eng.read_loss() - lref) < tol * lref
@@ -236,3 +247,52 @@ def test_golden_glyph_fixtures_through_the_engine():
             assert abs(eng.read_loss() - float(tw[f"{tag}/losses"][i])) < 3e-6, (tag, i)
         for k, v in eng.state_dict().items():
             assert maxabs(v.cpu().numpy(), tw[f"{tag}/param3/{k}"]) < 2e-5, (tag, k)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("cfgkw,B", [
+    (dict(hidden=(256,), out_h=16, out_w=16), 95),                          # C1: one ragged 16-/64-row block at the end
+    (dict(hidden=(64,), out_h=8, out_w=8, n_fonts=2), 300),                 # smallest shapes the fused kernel takes, with fonts
+    (dict(hidden=(192,), out_h=8, out_w=16, n_fonts=1, embed_dim=64), 130),  # wider embedding, widths that are not powers of 2
+])
+def test_fused_small_net_step_equals_the_per_layer_kernels(cfgkw, B, dtype):
+    """afr_train_step on a small one-hidden-layer glyph net is ONE fused kernel + the grouped reduce (glyph_fused.hip).
+    f32: the same step through the generic per-layer kernels (config flag bit 2) -- gradients, loss and three optimizer
+    steps agree to accumulation-order rounding.  bf16: the two paths round at different points (the fused kernel takes
+    bf16 operands in every product, the generic path evaluates fc1 from f32 tables), so each is held to the oracle rounded
+    at ITS points instead."""
+    cfg = GlyphConfig(**cfgkw)
+    assert fused1_eligible(cfg)
+    x, font, tu8 = glyph_inputs(cfg, B)
+    xt, ft, tt = torch.from_numpy(x), torch.from_numpy(font) if cfg.n_fonts else None, torch.from_numpy(tu8)
+    a = _engine(cfg, dtype=dtype, max_batch=B)
+    a.train_step(xt, tt, font=ft, do_step=False)
+    la = a.read_loss()
+    if dtype == "f32":
+        b = _engine(cfg, dtype=dtype, max_batch=B, flags=4)
+        b.train_step(xt, tt, font=ft, do_step=False)
+        lb = b.read_loss()
+        assert abs(la - lb) <= 2e-6 * lb
+        for k in a.grads:
+            assert _rel(a.grads[k].cpu().numpy(), b.grads[k].cpu().numpy()) < 2e-5, k
+        for _ in range(3):
+            a.train_step(xt, tt, font=ft)
+            b.train_step(xt, tt, font=ft)
+        assert abs(a.read_loss() - b.read_loss()) < 1e-5 * 3
+        for k in a.params:
+            assert float((a.params[k] - b.params[k]).abs().max()) < 2e-5, k
+    else:
+        rnd = engine_rounding(cfg, dtype, train_step=True)
+        P = tparams(cfg)
+        _, cache = oracle.glyph_forward(P, xt, torch.from_numpy(font), cfg, rnd=rnd)
+        lref, du = oracle.mse_loss_grad(cache["u"], torch.from_numpy(tu8.astype(np.float32) / 255.0))
+        Gref = oracle.glyph_backward(P, cache, rnd_du(rnd, du), cfg, rnd=rnd)
+        assert abs(la - float(lref)) < 3e-2 * float(lref)
+        for k in a.grads:
+            assert _rel(a.grads[k].cpu().numpy(), Gref[k].numpy()) < 3e-2, k
+    assert a.error_flags() == 0
+    # run-to-run bitwise reproducibility of the fused step (slabs are summed in block order)
+    a.train_step(xt, tt, font=ft, do_step=False)
+    g1 = a.flat_grads.clone()
+    a.train_step(xt, tt, font=ft, do_step=False)
+    assert torch.equal(g1, a.flat_grads)

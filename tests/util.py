@@ -45,7 +45,15 @@ def glyph_inputs(cfg, B, seed=0):
 
 
 # ---------------------------------------------------------------- rounding points of the bf16 (throughput) engine
-def engine_rounding(cfg, dtype):
+def fused1_eligible(cfg):
+    """Mirror of afr_glyph1_eligible (csrc/glyph_fused.hip): the nets afr_train_step runs as ONE fused kernel."""
+    if getattr(cfg, "kind", "") != "glyph" or len(cfg.hidden) != 1:
+        return False
+    E, N1, P = cfg.embed_dim, cfg.hidden[0], cfg.pixels
+    return E % 32 == 0 and E <= 64 and N1 % 64 == 0 and N1 <= 256 and P % 64 == 0 and P <= 256 and cfg.vocab + cfg.n_fonts <= 264
+
+
+def engine_rounding(cfg, dtype, train_step=False):
     """Rounding hook for the oracle (oracle.linear_fwd/dw/dx sites) that mimics where the HIP engine's bf16 mode
     rounds to bfloat16.  This is knowledge about the IMPLEMENTATION UNDER TEST and lives with its tests; the oracle
     itself stays the reference's plain f32 arithmetic (rnd=None).  Returns None for the f32 (parity) mode.
@@ -54,7 +62,9 @@ def engine_rounding(cfg, dtype):
     epilogues are f32, stored results are bf16.  Exception -- the glyph model's FOLDED first layer (csrc/elementwise.hip
     glyph_table/l1 kernels, used when 0 < hidden layers and K0 = E + vocab + fonts <= 512 and E <= 128): fc1 is evaluated
     from the f32 tables and f32 W1 (only its result h1 is rounded), and its input gradient is folded into f32 table-row
-    sums (no rounded d0, f32 W1); the stored h0' that feeds dW1 IS bf16."""
+    sums (no rounded d0, f32 W1); the stored h0' that feeds dW1 IS bf16.
+    train_step=True on a net afr_train_step runs as one fused kernel (csrc/glyph_fused.hip): every product takes bf16
+    operands (h0, W1 included), the embedding-row gradient dh0 too (it feeds the one-hot scatter product)."""
     if dtype != "bf16":
         return None
     b16 = oracle.bf16_round
@@ -63,6 +73,8 @@ def engine_rounding(cfg, dtype):
         k0 = cfg.embed_dim + (cfg.vocab + cfg.n_fonts + 7) // 8 * 8
         folded = k0 <= 512 and cfg.embed_dim <= 128
     unrounded = {"fc1.fwd.x", "fc1.fwd.w", "fc1.dx.w", "fc1.dx.y"} if folded else set()
+    if train_step and fused1_eligible(cfg):
+        unrounded = set()
 
     def rnd(t, site=None):
         return t if site in unrounded else b16(t)
