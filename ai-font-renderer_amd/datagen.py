@@ -56,6 +56,26 @@ def render_sheet(text, font):
     return np.asarray(img, dtype=np.uint8)
 
 
+def render_glyphs(font_paths, size, codes=range(32, 127)):
+    """Per-glyph targets of the BASELINE glyph configs: for every font and every printable ASCII code one size x size
+    bitmap, white background, black glyph (the generate_font.ts:112-142 idiom -- fillStyle white, fillText black -- at
+    glyph scale): the glyph is drawn with its advance box centred horizontally and the font's ascent/descent box centred
+    vertically, at a pixel size of 0.8 * size.  uint8 [n_fonts, n_codes, size, size]."""
+    from PIL import Image, ImageDraw, ImageFont
+    out = np.zeros((len(font_paths), len(codes), size, size), dtype=np.uint8)
+    for fi, path in enumerate(font_paths):
+        font = ImageFont.truetype(path, int(round(size * 0.8)))
+        ascent, descent = font.getmetrics()
+        y0 = (size - (ascent + descent)) / 2.0 + ascent
+        for ci, code in enumerate(codes):
+            img = Image.new("L", (size, size), 255)
+            ch = chr(code)
+            x0 = (size - font.getlength(ch)) / 2.0
+            ImageDraw.Draw(img).text((x0, y0), ch, fill=0, font=font, anchor="ls")
+            out[fi, ci] = np.asarray(img, dtype=np.uint8)
+    return out
+
+
 def generate(out_dir, n, font_path=None, first_seed=42):
     """font_path=None falls back to Pillow's built-in scalable font (tests; the real data set uses Fira Code)."""
     from PIL import ImageFont

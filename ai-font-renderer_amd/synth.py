@@ -167,3 +167,25 @@ def sheet_dropout_masks(cfg, B, L, seed, step, rank=0):
     mf = dropout_keep_mask(dropout_key(seed, step, STREAM_FC, rank), B * L * F, 1.0 - cfg.p_fc)
     return dict(embed=me.reshape(B, L, E).astype(np.uint8), attn=ma.reshape(B, H, L, L).astype(np.uint8),
                 fc=mf.reshape(B, L, F).astype(np.uint8))
+
+
+# ---------------------------------------------------------------- rasterised glyph targets (BASELINE C1-C4)
+_GLYPH_FIXTURE = None
+
+
+def glyph_bitmap_targets(size, x, font=None):
+    """uint8 [B, size, size] targets for codes x (32..126) and font ids: the FreeType rasterisations of FiraCode-Retina
+    (16x16; font 0 of 32x32) and Montserrat-Regular (font 1 of 32x32) that tests/golden/make_golden.py drew with
+    datagen.render_glyphs from the reference's two TTFs.  None when the fixture file is not there or holds no such size."""
+    global _GLYPH_FIXTURE
+    import os
+    if _GLYPH_FIXTURE is None:
+        path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "glyph_bitmaps.npz")
+        _GLYPH_FIXTURE = dict(np.load(path)) if os.path.exists(path) else {}
+    x = np.asarray(x, dtype=np.int64)
+    if size == 16 and "fira16" in _GLYPH_FIXTURE:
+        return _GLYPH_FIXTURE["fira16"][x - 32]
+    if size == 32 and "fira_mont32" in _GLYPH_FIXTURE:
+        f = np.zeros_like(x) if font is None else np.asarray(font, dtype=np.int64)
+        return _GLYPH_FIXTURE["fira_mont32"][f, x - 32]
+    return None

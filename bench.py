@@ -13,8 +13,9 @@ Workloads (BASELINE.json configs) -- per-GPU batch is fixed, so sc
   c2            16x16 glyphs, hidden 256, bf16, 4096 glyphs (configs[1]; launch-latency bound)
   c1            same net, fp32, 95 glyphs (configs[0], the CPU-runnable case)
   r0            the reference's own AttentionFontRenderer (80x240 sheets of <=100 chars), 1024 sheets per GPU
-Inputs (codes, font ids, uint8 target bitmaps) are synthetic (counter hash / seeded text generator) and resident in
-HBM before the timed region.  A step = the loop body of reference model.py:292-310.  Prints ONE JSON line on rank 0.
+Inputs are synthetic and resident in HBM before the timed region: the 95 printable ASCII codes (x font ids) repeated over
+the batch, with the FreeType rasterisations of FiraCode-Retina / Montserrat-Regular as uint8 targets (tests/golden/
+glyph_bitmaps.npz); R0: strings from the seeded text generator, hashed sheets.  A step = the loop body of reference model.py:292-310.  Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
@@ -53,7 +54,9 @@ def make_inputs(name, cfg, B, rank):
     i = np.arange(rank * B, (rank + 1) * B)
     x = (32 + (i % 95)).astype(np.int64)                              # the 95 printable ASCII codes, repeated
     font = ((i // 95) % max(cfg.n_fonts, 1)).astype(np.int64)
-    t = synth.hash_u8(950 + rank, (B, cfg.out_h, cfg.out_w))
+    t = synth.glyph_bitmap_targets(cfg.out_h, x, font) if cfg.out_h == cfg.out_w else None     # FiraCode (+ Montserrat) glyphs
+    if t is None:
+        t = synth.hash_u8(950 + rank, (B, cfg.out_h, cfg.out_w))
     return torch.from_numpy(x), (torch.from_numpy(font) if cfg.n_fonts > 0 else None), torch.from_numpy(t)
 
 

@@ -23,6 +23,13 @@ stored.  What is captured:
                   reference class cannot express: a small net with a font table and two hidden layers (eval output, loss,
                   all gradients, 3 AdamW steps) and BASELINE C1 (16x16, hidden 256, batch 95: losses + parameters after 3
                   steps + step-1 gradients)
+  glyph_bitmaps.npz  the rasterised targets of the BASELINE glyph configs: FiraCode-Retina 95 printable ASCII at 16x16 (C1/C2) and
+                  FiraCode-Retina + Montserrat-Regular at 32x32 (C3/C4), drawn with PIL/FreeType by
+                  ai_font_renderer_amd.datagen.render_glyphs from the two TTFs the reference ships (data, read only here)
+  train_loop.npz  the reference's own train_attention_model (model.py:209-384) on an 80-sheet mini dataset (8x24 sheets, 10
+                  characters, batch 16, dropout off, plateau patience 1, early-stop patience 4, <= 16 epochs; run "a" LR 0.004, run "b" LR 0.03):
+                  per-epoch validation loss and learning rate as its scheduler saw them, the train losses it printed, its
+                  training_results.txt, and the parameters it ended with
   helpers.npz     binary_array_to_image truncation (helpers.py:33), image_to_binary_array (helpers.py:121)
                   on a 24-bit top-down BMP written per generate_font.ts:6-62
 """
@@ -302,6 +309,87 @@ def glyph_twin():
     print("glyph_twin.npz", {k: fx[k].shape for k in list(fx)[:6]})
 
 
+def glyph_bitmaps():
+    from ai_font_renderer_amd import datagen
+    fonts = ["/root/reference/FiraCode-Retina.ttf", "/root/reference/Montserrat-Regular.ttf"]
+    g16 = datagen.render_glyphs(fonts[:1], 16)            # [1, 95, 16, 16]
+    g32 = datagen.render_glyphs(fonts, 32)                # [2, 95, 32, 32]
+    np.savez_compressed(os.path.join(OUT, "glyph_bitmaps.npz"), fira16=g16[0], fira_mont32=g32)
+    print("glyph_bitmaps.npz", g16.shape, g32.shape, "dark fraction", float((g32 < 128).mean()))
+
+
+def train_loop():
+    """Two runs of the reference's training driver: "a" learns steadily for 16 epochs (LR 0.004); "b" (LR 0.03) overshoots,
+    so the plateau scheduler cuts the rate and early stopping ends the run."""
+    fx = {}
+    for tag, lr in (("a", 0.004), ("b", 0.03)):
+        for k, v in _train_loop_run(lr).items():
+            if tag == "b" and k.startswith("final/"):
+                continue                                    # a saturated run's parameters say nothing; its bookkeeping does
+            fx[f"{tag}/{k}"] = v
+    np.savez_compressed(os.path.join(OUT, "train_loop.npz"), **fx)
+
+
+def _train_loop_run(lr_):
+    """The reference's training driver itself (model.py:209-384): data split, loaders, AdamW, ReduceLROnPlateau, early
+    stopping, artefacts -- on a dataset small enough to run here, with its own constants turned down."""
+    import contextlib
+    cfg = SheetConfig(max_length=10, sheet_h=8, sheet_w=24)
+    N, BS = 80, 16
+    saved = {k: getattr(ref, k) for k in ("NUM_EPOCHS", "LEARNING_RATE", "SCHEDULER_PATIENCE", "EARLY_STOPPING_PATIENCE", "OUTPUT_DIR",
+                                          "SHEET_HEIGHT", "SHEET_WIDTH", "MAX_CHARS_PER_SHEET")}
+    tmp = tempfile.mkdtemp()
+    try:
+        ref.NUM_EPOCHS, ref.LEARNING_RATE, ref.SCHEDULER_PATIENCE, ref.EARLY_STOPPING_PATIENCE = 16, lr_, 1, 4
+        ref.OUTPUT_DIR, ref.MAX_CHARS_PER_SHEET = os.path.join(tmp, "out"), 10
+        m = build_ref(cfg)                                       # also sets ref.SHEET_HEIGHT / WIDTH
+        m.embedding_dropout.p = 0.0
+        m.dropout1.p = 0.0
+        m.attention.dropout = 0.0
+        x = torch.from_numpy(synth.encode_strings(synth.dataset_strings(N), 10))
+        # a LEARNABLE synthetic target (hash noise would saturate at its variance within an epoch): the pixel at (h, w) shows
+        # the code under it -- character (10 w) // 24 of the string -- as a grey level, shifted by the row
+        xs = x.numpy()
+        tu8 = ((xs[:, (np.arange(24) * 10) // 24][:, None, :] * 7 + np.arange(8)[None, :, None] * 16) % 256).astype(np.uint8)
+        ds = torch.utils.data.TensorDataset(x, torch.from_numpy(tu8.astype(np.float32) / 255.0))
+        log = []
+        Sched = torch.optim.lr_scheduler.ReduceLROnPlateau
+        orig_step = Sched.step
+
+        def step(self, metrics, *a, **k):
+            r = orig_step(self, metrics, *a, **k)
+            log.append((float(metrics), float(self.optimizer.param_groups[0]["lr"])))
+            return r
+
+        Sched.step = step
+        buf = io.StringIO()
+        try:
+            with contextlib.redirect_stdout(buf):
+                ref.train_attention_model(m, ds, BS)
+        finally:
+            Sched.step = orig_step
+        printed = {}
+        for line in buf.getvalue().splitlines():
+            if line.startswith("Epoch ") and "Train Loss:" in line:
+                ep = int(line.split(",")[0].split()[1])
+                printed[ep] = float(line.split("Train Loss:")[1].split(",")[0])
+        results = open(os.path.join(ref.OUTPUT_DIR, "training_results.txt")).read().splitlines()
+        results = [ln for ln in results if not ln.startswith("training_completed")]
+        fx = dict(x=x.numpy(), target_u8=tu8, val_losses=np.array([v for v, _ in log], dtype=np.float32),
+                  lrs=np.array([lr for _, lr in log], dtype=np.float64),
+                  printed_epochs=np.array(sorted(printed), dtype=np.int64),
+                  printed_train_losses=np.array([printed[e] for e in sorted(printed)], dtype=np.float32),
+                  results=np.array("\n".join(results)), stdout=np.array(buf.getvalue()))
+        for k, v in m.state_dict().items():
+            fx["final/" + k] = v.detach().numpy()
+        print("train_loop run lr", lr_, "epochs", len(log), "val", [round(v, 5) for v, _ in log], "lr", [lr for _, lr in log])
+        print("\n".join(results))
+        return fx
+    finally:
+        for k, v in saved.items():
+            setattr(ref, k, v)
+
+
 def bmp24_topdown(rgb):
     """24-bit BGR top-down BMP bytes in the layout generate_font.ts:6-62 writes."""
     import struct
@@ -337,6 +425,6 @@ def helpers_fx():
 
 if __name__ == "__main__":
     only = sys.argv[1:]
-    for fn in (glyph_ref1, glyph_twin, mini, helpers_fx, r0):
+    for fn in (glyph_ref1, glyph_twin, glyph_bitmaps, train_loop, mini, helpers_fx, r0):
         if not only or fn.__name__ in only:
             fn()

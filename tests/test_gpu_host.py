@@ -172,6 +172,61 @@ def test_train_string_renderer_end_to_end(tmp_path, monkeypatch):
     assert (tmp_path / "render_only" / "string_0.bmp").exists()
 
 
+@pytest.mark.parametrize("run", ["a", "b"])
+def test_training_loop_replays_the_references_own_trajectory(tmp_path, monkeypatch, capsys, run):
+    """train_attention_model against tests/golden/train_loop.npz: the REFERENCE's train_attention_model (model.py:209-384)
+    run on the same 80 sheets with the same constants.  Same split, same batch order, same mean-of-batch-means, same
+    scheduler and early-stopping decisions: per-epoch validation loss and learning rate, the printed train losses,
+    training_results.txt and (run a) the final parameters."""
+    from dataclasses import replace
+    from ai_font_renderer_amd import model as M
+    from ai_font_renderer_amd.engine import Engine
+    fx = load("train_loop.npz")
+    lr0 = float(fx[run + "/lrs"][0])
+    monkeypatch.chdir(tmp_path)
+    for k, v in dict(NUM_EPOCHS=16, LEARNING_RATE=lr0, SCHEDULER_PATIENCE=1, EARLY_STOPPING_PATIENCE=4, OUTPUT_DIR="loop_out",
+                     SHEET_HEIGHT=8, SHEET_WIDTH=24, MAX_CHARS_PER_SHEET=10).items():
+        monkeypatch.setattr(M, k, v)
+    m = M.AttentionFontRenderer(max_length=10, max_batch=16, init=False)
+    # the fixture was captured with the three dropouts off: an engine with zero rates, parameters re-pointed (as above)
+    m.engine = Engine(replace(m.config, p_embed=0.0, p_attn=0.0, p_fc=0.0), dtype="f32", max_batch=16, device=M.device)
+    m.engine.load_params(synth.make_params(MINI))
+    P = {k: torch.nn.Parameter(v) for k, v in m.engine.params.items()}
+    for name in KEYS:
+        mod_, _, attr = name.rpartition(".")
+        (m.get_submodule(mod_) if mod_ else m)._parameters[attr] = P[name]
+    ds = torch.utils.data.TensorDataset(torch.from_numpy(fx[run + "/x"]), torch.from_numpy(fx[run + "/target_u8"].astype(np.float32) / 255.0))
+    log = []
+    Sched = torch.optim.lr_scheduler.ReduceLROnPlateau
+    orig = Sched.step
+
+    def step(self, metrics, *a, **k):
+        r = orig(self, metrics, *a, **k)
+        log.append((float(metrics), float(self.optimizer.param_groups[0]["lr"])))
+        return r
+
+    monkeypatch.setattr(Sched, "step", step)
+    M.train_attention_model(m, ds, 16)
+    val, lrs = np.array([v for v, _ in log]), np.array([l for _, l in log])
+    assert len(val) == len(fx[run + "/val_losses"])                      # same number of epochs: same stopping decision
+    assert np.allclose(lrs, fx[run + "/lrs"], rtol=1e-12)                # same plateau decisions
+    assert np.abs(val / fx[run + "/val_losses"] - 1).max() < 1e-4
+    out = capsys.readouterr().out
+    printed = {int(l.split(",")[0].split()[1]): float(l.split("Train Loss:")[1].split(",")[0]) for l in out.splitlines()
+               if l.startswith("Epoch ") and "Train Loss:" in l}
+    assert sorted(printed) == list(fx[run + "/printed_epochs"])
+    assert np.abs(np.array([printed[e] for e in sorted(printed)]) / fx[run + "/printed_train_losses"] - 1).max() < 2e-4
+    res = [l for l in (tmp_path / "loop_out" / "training_results.txt").read_text().splitlines() if not l.startswith("training_completed")]
+    assert res == str(fx[run + "/results"]).splitlines()
+    if run == "a":
+        E = MINI.embed_dim
+        for k, v in m.state_dict().items():
+            got, ref = v.cpu().numpy(), fx["a/final/" + k]
+            if k == "attention.in_proj_bias":      # k-bias: analytically zero gradient, Adam turns rounding noise into steps
+                got, ref = np.delete(got, np.s_[E:2 * E]), np.delete(ref, np.s_[E:2 * E])
+            assert maxabs(got, ref) < 2e-3 * max(1.0, float(np.abs(ref).max())), k
+
+
 def test_training_reduces_the_loss_on_a_fixed_batch():
     from ai_font_renderer_amd.engine import Engine
     from .util import SheetConfig
@@ -198,3 +253,32 @@ def test_library_loaded_before_torch_still_shares_one_hip_runtime():
             "import __graft_entry__ as g; g.smoke()")
     r = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "smoke ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_c1_learns_the_firacode_glyphs():
+    """BASELINE configs[0] end to end on its real targets: the 95 printable ASCII glyphs of FiraCode-Retina at 16x16
+    (tests/golden/glyph_bitmaps.npz, rasterised from the reference's TTF), 2-layer MLP, f32, batch 95.  800 AdamW steps
+    of the fused step: the bitmaps the model then draws are the targets to within a few grey levels."""
+    from ai_font_renderer_amd.config import WORKLOADS
+    from ai_font_renderer_amd.engine import Engine
+    cfg = WORKLOADS["c1"]["cfg"]
+    x = np.arange(32, 127, dtype=np.int64)
+    t = synth.glyph_bitmap_targets(16, x)
+    assert t is not None and t.shape == (95, 16, 16) and t.dtype == np.uint8 and (t < 128).mean() > 0.03
+    eng = Engine(cfg, dtype="f32", max_batch=95)
+    eng.load_params(synth.make_params(cfg))
+    xt, tt = torch.from_numpy(x), torch.from_numpy(t)
+    first = None
+    for i in range(800):
+        eng.train_step(xt, tt, lr=3e-3)
+        if i == 0:
+            first = eng.read_loss()
+    eng.read_loss()
+    eng.train_step(xt, tt, do_step=False)
+    last = eng.read_loss()
+    y = eng.forward(xt).cpu().numpy()
+    err = np.abs(y - t.astype(np.float32) / 255.0)
+    print("c1 on FiraCode: loss", first, "->", last, " mean |err|", float(err.mean()), " pixels on the right side of 0.5:", float(((y > 0.5) == (t > 127)).mean()))
+    assert last < 0.03 * first
+    assert err.mean() < 0.03
+    assert ((y > 0.5) == (t > 127)).mean() > 0.96          # the drawn glyphs are the FiraCode glyphs (dead clamp pixels aside)
