@@ -220,6 +220,14 @@ class Engine:
         self.t += 1
         self._call(self.lib.afr_adamw_step, self._plan, lr, betas[0], betas[1], eps, weight_decay, self.t, grad_scale)
 
+    def adamw_range(self, offset, n, lr=1e-3, betas=(0.9, 0.99), eps=1e-8, weight_decay=5e-4, grad_scale=1.0):
+        """One AdamW step on the flat-buffer slice [offset, offset + n) only (sharded optimizer under data parallelism:
+        parallel.py).  Advances the step counter; the bf16 shadow is NOT refreshed (the caller syncs after its all-gather)."""
+        self.t += 1
+        o, e = int(offset), int(offset) + int(n)
+        self._call(self.lib.afr_op_adamw, _ptr(self.flat_params[o:e]), _ptr(self.flat_grads[o:e]), _ptr(self.exp_avg[o:e]),
+                   _ptr(self.exp_avg_sq[o:e]), C.c_void_p(0), int(n), lr, betas[0], betas[1], eps, weight_decay, self.t, grad_scale)
+
     def train_step(self, x, target, font=None, step=None, lr=1e-3, betas=(0.9, 0.99), eps=1e-8, weight_decay=5e-4,
                    mean_elems=None, do_step=True):
         """zero_grad -> forward -> loss -> backward -> AdamW, one C call (model.py:292-310)."""

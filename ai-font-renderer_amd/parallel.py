@@ -28,16 +28,52 @@ def shard_rows(n_rows, rank, world):
 # Below this gradient size the step uses ONE all-reduce after a monolithic backward: the overlapped two-collective
 # schedule costs ~33 us of staging and cross-stream hand-offs per step (measured with a world of one on the 8.5 MB C3
 # model: 274 us against 240 us), more than the transfer time it could hide.  The sheet model (492 MB) overlaps.
-OVERLAP_MIN_BYTES = 64 << 20
+OVERLAP_MIN_BYTES = int(os.environ.get("AFR_DP_OVERLAP_MIN_BYTES", 64 << 20))
+# From this gradient size on (the sheet model: 492 MB, 99.98 % of it one tensor) the optimizer state is SHARDED over the
+# ranks instead of replicated: reduce-scatter of the flat gradient buffer -> AdamW on this rank's 1/N slice only (1/N of
+# the 28 B/parameter of optimizer traffic, 3.4 GB per step for the sheet model) -> all-gather of the updated parameters.
+# Same bytes on the links as the all-reduce it replaces (which is a reduce-scatter + all-gather inside RCCL), parameters
+# stay bit-identical on every rank; exp_avg / exp_avg_sq are only meaningful inside a rank's own slice.
+SHARD_MIN_BYTES = int(os.environ.get("AFR_DP_SHARD_MIN_BYTES", 64 << 20))
 # AFR_DP_GRAD_BF16=1 (opt-in, throughput mode only): exchange the gradients as bf16 -- half the bytes on the xGMI links
 # at the price of rounding each rank's gradient to 8 significant bits before the sum (the exact-f32 exchange is the default
 # and what the data-parallel tests pin).  Meant for link-bound small models; unmeasured on a multi-GPU node so far.
 GRAD_BF16 = os.environ.get("AFR_DP_GRAD_BF16") == "1"
 
 
+def _reduce_scatter_inplace(dist, flat, rank, world):
+    """Sum `flat` over the ranks; afterwards this rank's slice [rank*n/world, (rank+1)*n/world) holds the sum (the rest is
+    unspecified).  RCCL: a true in-place reduce-scatter; backends without one (gloo, CPU tests) fall back to an all-reduce."""
+    n = flat.numel() // world
+    mine = flat[rank * n:(rank + 1) * n]
+    try:
+        dist.reduce_scatter_tensor(mine, flat)
+    except (RuntimeError, NotImplementedError, ValueError):
+        dist.all_reduce(flat)
+    return mine
+
+
+def _all_gather_inplace(dist, flat, rank, world):
+    """Every rank contributes its slice of `flat`; afterwards all of `flat` is identical everywhere."""
+    n = flat.numel() // world
+    try:
+        dist.all_gather_into_tensor(flat, flat[rank * n:(rank + 1) * n].clone() if flat.device.type == "cpu" else flat[rank * n:(rank + 1) * n])
+    except (RuntimeError, NotImplementedError, ValueError):
+        parts = [torch.empty(n, dtype=flat.dtype, device=flat.device) for _ in range(world)]
+        dist.all_gather(parts, flat[rank * n:(rank + 1) * n].clone())
+        for r, part in enumerate(parts):
+            flat[r * n:(r + 1) * n].copy_(part)
+
+
 class DataParallelStepper:
-    def __init__(self, engine, dist=None, world=1):
+    def __init__(self, engine, dist=None, world=1, rank=None):
         self.engine, self.dist, self.world = engine, dist, int(world)
+        self.rank = int(rank) if rank is not None else (dist.get_rank() if (dist is not None and self.world > 1 and dist.is_initialized()) else 0)
+
+    def sharded(self):
+        eng = self.engine
+        return (self.world > 1 and hasattr(eng, "adamw_range") and eng.flat_grads.numel() * 4 >= SHARD_MIN_BYTES
+                and eng.flat_grads.numel() % self.world == 0 and self.dist.get_world_size() == self.world)
 
     def step(self, x, target, font=None, mean_elems=None, **hyper):
         """One optimiser step on this rank's shard.  mean_elems = global_rows * pixels."""
@@ -47,7 +83,7 @@ class DataParallelStepper:
             return
         opt = {k: v for k, v in hyper.items() if k in ("lr", "betas", "eps", "weight_decay")}
         stages = getattr(eng, "backward_stages", 0)
-        if stages and eng.flat_grads.numel() * 4 >= OVERLAP_MIN_BYTES:
+        if stages and eng.flat_grads.numel() * 4 >= OVERLAP_MIN_BYTES and not (self.sharded() and os.environ.get("AFR_DP_SCHEDULE", "shard") == "shard"):
             # Backward runs last layer first.  Two collectives per step: the last layer's gradient range (half of the
             # bytes in the glyph nets, 99.98 % in the sheet model) is all-reduced ASYNCHRONOUSLY as soon as stage 0 has
             # produced it and overlaps the rest of the backward pass; everything else is one contiguous range
@@ -62,6 +98,16 @@ class DataParallelStepper:
             if rest.numel():
                 self.dist.all_reduce(rest)
             work.wait()
+        elif self.sharded():
+            # sharded optimizer: backward -> reduce-scatter -> AdamW on this rank's slice -> all-gather of the parameters
+            eng.train_step(x, target, font=font, mean_elems=mean_elems, do_step=False, **hyper)
+            n = eng.flat_grads.numel() // self.world
+            _reduce_scatter_inplace(self.dist, eng.flat_grads, self.rank, self.world)
+            eng.adamw_range(self.rank * n, n, **opt)
+            _all_gather_inplace(self.dist, eng.flat_params, self.rank, self.world)
+            if hasattr(eng, "sync_params"):
+                eng.sync_params()               # bf16 mode: the shadow of the slices other ranks updated
+            return
         else:
             eng.train_step(x, target, font=font, mean_elems=mean_elems, do_step=False, **hyper)
             if GRAD_BF16 and getattr(eng, "dtype", "f32") == "bf16":

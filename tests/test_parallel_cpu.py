@@ -19,9 +19,15 @@ class OracleEngine:
         from ai_font_renderer_amd.config import flat_layout
         self.cfg = cfg
         self.table, n = flat_layout(cfg)
-        self.P = tparams(cfg)
-        self.M = {k: torch.zeros_like(v) for k, v in self.P.items()}
-        self.V = {k: torch.zeros_like(v) for k, v in self.P.items()}
+        # flat buffers in the engine's layout; the per-tensor dicts are views into them
+        self.flat_params, self.flat_m, self.flat_v = torch.zeros(n), torch.zeros(n), torch.zeros(n)
+        init = tparams(cfg)
+        self.P, self.M, self.V = {}, {}, {}
+        for name, shape, off, k in self.table:
+            self.P[name] = self.flat_params[off:off + k].view(shape)
+            self.P[name].copy_(init[name])
+            self.M[name] = self.flat_m[off:off + k].view(shape)
+            self.V[name] = self.flat_v[off:off + k].view(shape)
         self.flat_grads = torch.zeros(n)
         self.loss_accum = torch.zeros(1)
         self.t = 0
@@ -38,27 +44,37 @@ class OracleEngine:
             self.adamw_step(**hyper)
 
     def adamw_step(self, **hyper):
+        self.adamw_range(0, self.flat_params.numel(), **hyper)
+
+    def adamw_range(self, offset, n, **hyper):
+        """AdamW is element-wise: a slice of the flat buffers is a valid unit of work (the sharded optimizer's)."""
         self.t += 1
-        for name, shape, off, n in self.table:
-            g = self.flat_grads[off:off + n].view(shape)
-            self.P[name], self.M[name], self.V[name] = oracle.adamw_step(self.P[name], g, self.M[name], self.V[name], self.t)
+        sl = slice(offset, offset + n)
+        p, m, v = oracle.adamw_step(self.flat_params[sl], self.flat_grads[sl], self.flat_m[sl], self.flat_v[sl], self.t)
+        self.flat_params[sl], self.flat_m[sl], self.flat_v[sl] = p, m, v
 
 
 CFG = GlyphConfig(hidden=(24, 16), out_h=4, out_w=4, n_fonts=2)
 ROWS = 37          # uneven over 2 ranks: 19 + 18
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, shard=False):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    from ai_font_renderer_amd import parallel
     from ai_font_renderer_amd.parallel import DataParallelStepper, shard_rows
+    if shard:
+        parallel.SHARD_MIN_BYTES = 0          # take the sharded-optimizer schedule for this small net too
+    else:
+        parallel.SHARD_MIN_BYTES = 1 << 60
     torch.set_num_threads(1)
     x, font, t = glyph_inputs(CFG, ROWS)
     sl = shard_rows(ROWS, rank, world)
     eng = OracleEngine(CFG)
     st = DataParallelStepper(eng, dist, world)
+    assert st.sharded() == shard
     for _ in range(3):
         st.step(torch.from_numpy(x[sl]), torch.from_numpy(t[sl]), torch.from_numpy(font[sl]), mean_elems=ROWS * CFG.pixels)
     loss = st.global_loss()
@@ -67,14 +83,21 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_two_rank_data_parallel_equals_full_batch():
+import pytest
+
+
+@pytest.mark.parametrize("shard", [False, True])
+def test_two_rank_data_parallel_equals_full_batch(shard):
+    """shard=False: sum all-reduce of the flat gradients + replicated AdamW.  shard=True: reduce-scatter -> AdamW on each
+    rank's half of the flat buffers -> all-gather of the parameters (the schedule of the 492 MB sheet model)."""
     from ai_font_renderer_amd.parallel import DataParallelStepper, shard_rows
     assert [shard_rows(37, r, 2) for r in range(2)] == [slice(0, 19), slice(19, 37)]
     assert sum(s.stop - s.start for s in (shard_rows(8192 * 8 + 5, r, 8) for r in range(8))) == 8192 * 8 + 5
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 29500 + os.getpid() % 2000
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    port += 1 if shard else 0
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, shard)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=120) for _ in procs], key=lambda r: r[0])
@@ -90,7 +113,8 @@ def test_two_rank_data_parallel_equals_full_batch():
     full_loss = st.global_loss()
     for rank, P, g, loss in res:
         assert abs(loss - full_loss) < 1e-6 * full_loss
-        assert np.abs(g - eng.flat_grads.numpy()).max() < 1e-6 * np.abs(g).max()
+        if not shard:                                       # (sharded: only a rank's own half of the buffer holds the sum)
+            assert np.abs(g - eng.flat_grads.numpy()).max() < 1e-6 * np.abs(g).max()
         for k in P:
             assert np.abs(P[k] - eng.P[k].numpy()).max() < 2e-6, (rank, k)
     for k in res[0][1]:                                     # replicas stay bit-identical to each other
