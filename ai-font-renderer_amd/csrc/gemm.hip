@@ -534,7 +534,64 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmParams& p, const int bi
     const i32x4 rA = make_rsrc(A), rB = make_rsrc(B);
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
 
+    // Interior blocks (whole tile inside M x N, K range a multiple of 64) address their DMA pieces the FAST way: the
+    // lane-dependent part of a piece's source offset depends on the lane and the wave only (for k-strided A images also
+    // on whether the piece is in the wave's first or second pair), so it is computed once; which piece and which K-tile
+    // are wave-uniform byte offsets passed as the instruction's SGPR soffset -- no per-piece address arithmetic, bounds
+    // selects or exec-mask juggling inside the K loop.
+    const bool fast = (m0 + BM <= p.M) && (n0 + BN <= p.N) && ((kend - kbeg) % BK == 0) && nt > 0;
+    unsigned fvA[2] = {0, 0}, fvB[2] = {0, 0};         // [first | second half of the wave's pieces] (equal unless k-strided)
+    {
+        const int ia0 = (wave * A_PER_WAVE) & 15, asub = (wave * A_PER_WAVE) >> 4, ib0 = wave * B_PER_WAVE;
+        if (ALAY == 0) {
+            const int r8 = lane >> 3;
+            fvA[0] = fvA[1] = (unsigned)(((size_t)(m0 + asub * 128 + ia0 * 8 + r8) * p.lda + kbeg + 8 * ((lane & 7) ^ (r8 & 7))) * 2);
+        } else {
+            const int q4 = lane >> 4;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int hi = A_PER_WAVE >= 4 ? h : ((ia0 >> 1) & 1);
+                const int c = (lane & 15) ^ (((q4 & 3) | (hi << 2)) << 1);
+                fvA[h] = (unsigned)(((size_t)(kbeg + ia0 * 4 + q4) * p.lda + m0 + asub * 128 + 8 * c) * 2);
+            }
+        }
+        if (BLAY == 0) {
+            const int r8 = lane >> 3;
+            fvB[0] = fvB[1] = (unsigned)(((size_t)(n0 + ib0 * 8 + r8) * p.ldb + kbeg + 8 * ((lane & 7) ^ (r8 & 7))) * 2);
+        } else {
+            const int q4 = lane >> 4;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int hi = B_PER_WAVE >= 4 ? h : ((ib0 >> 1) & 1);
+                const int c = (lane & 15) ^ (((q4 & 3) | (hi << 2)) << 1);
+                fvB[h] = (unsigned)(((size_t)(kbeg + ib0 * 4 + q4) * p.ldb + n0 + 8 * c) * 2);
+            }
+        }
+    }
+    const unsigned fpA = (ALAY == 0 ? 8u : 4u) * p.lda * 2, fpB = (BLAY == 0 ? 8u : 4u) * p.ldb * 2;     // bytes per piece step
+    const unsigned ftA = ALAY == 0 ? 128u : 64u * p.lda * 2, ftB = BLAY == 0 ? 128u : 64u * p.ldb * 2;   // bytes per K-tile
+    auto dma_s = [&](i32x4 rsrc, unsigned lds_addr, unsigned voff, unsigned soff) {
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 3\n\tbuffer_load_dwordx4 %1, %4, %3 offen lds\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(voff), "s"(lds_addr), "s"(soff), "s"(rsrc) : "memory");
+    };
+    // piece q of the wave (q < A_PER_WAVE: A pieces, then B pieces) of K-tile t into ring slot `slot`
+    auto stage_piece_fast = [&](int t, int slot, int q) {
+        const unsigned S = lds0 + slot * STAGE_BYTES;
+        if (q < A_PER_WAVE) {
+            const int g = wave * A_PER_WAVE + q;
+            dma_s(rA, S + (g >> 4) * SUB + (g & 15) * 1024, fvA[A_PER_WAVE >= 4 ? (q >> 1) : 0], (unsigned)t * ftA + (unsigned)q * fpA);
+        } else {
+            const int i = q - A_PER_WAVE;
+            dma_s(rB, S + ASUB * SUB + (wave * B_PER_WAVE + i) * 1024, fvB[B_PER_WAVE >= 4 ? (i >> 1) : 0], (unsigned)t * ftB + (unsigned)i * fpB);
+        }
+    };
     auto stage = [&](int t, int slot) {
+        if (fast) {
+#pragma unroll
+            for (int q = 0; q < A_PER_WAVE + B_PER_WAVE; ++q) stage_piece_fast(t, slot, q);
+            return;
+        }
         const unsigned S = lds0 + slot * STAGE_BYTES;
         const int k0 = kbeg + t * BK;
 #pragma unroll
@@ -576,6 +633,7 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmParams& p, const int bi
     // k-step-1 MFMAs of tile t with the refill of the freed slot (tile t+3) and the fragment reads of tile t+1 (k-step 0)
     // issued BETWEEN the rows of MFMAs instead of ahead of them: the memory instructions go out while the matrix pipe works.
     auto stage_piece = [&](int t, int slot, int q) {
+        if (fast) { stage_piece_fast(t, slot, q); return; }
         const unsigned S = lds0 + slot * STAGE_BYTES;
         const int k0 = kbeg + t * BK;
         if (q < A_PER_WAVE) {
