@@ -12,25 +12,51 @@ import re
 import sys
 
 
+def rows(d):
+    """(kernel name, counter name, value) per dispatch of a rocprofv3 -d output: the csv of --output-format csv, or the
+    rocpd database ROCm 7.2 writes by default (its counters_collection view)."""
+    f = glob.glob(d + "/**/*_counter_collection.csv", recursive=True)
+    if f:
+        for r in csv.DictReader(open(f[0])):
+            yield r["Kernel_Name"], r["Counter_Name"], float(r["Counter_Value"])
+        return
+    import sqlite3
+    db = glob.glob(d + "/**/*_results.db", recursive=True)[0]
+    yield from sqlite3.connect(db).execute("select kernel_name, counter_name, value from counters_collection order by dispatch_id")
+
+
 def load(d):
-    f = glob.glob(d + "/*/*_counter_collection.csv")[0]
     acc = collections.defaultdict(list)
-    for r in csv.DictReader(open(f)):
-        acc[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+    for k, _, v in rows(d):
+        acc[k].append(v)
     return acc
 
 
+def kernel_stats(d):
+    """[(kernel, calls, total us, average us, percent)] from a --kernel-trace --stats run's rocpd database."""
+    import sqlite3
+    db = glob.glob(d + "/**/*_results.db", recursive=True)[0]
+    return list(sqlite3.connect(db).execute("select name, total_calls, total_duration, average, percentage from top_kernels"))
+
+
 def short(name):
-    m = re.search(r"(gemm_(?:bf16|f32)<[^>]*>)", name)
+    m = re.search(r"(gemm_bf16_group256|gemm_bf16_group|gemm_(?:bf16|f32)<[^>]*>)", name)
     if m:
         return m.group(1).replace(" ", "")
-    for k in ("sheet_bwd", "sheet_fwd", "adamw", "reduce_group", "mse_grad", "glyph_embed_bwd", "glyph_embed", "f32_to_bf16"):
+    for k in ("sheet_bwd", "sheet_fwd", "adamw", "reduce_group", "reduce_slabs", "mse_grad", "glyph1_step", "glyph_l1_fwd", "glyph_l1_bwd",
+              "glyph_table", "glyph_embed_bwd", "glyph_embed", "transpose_bf16", "f32_to_bf16", "clamp_out", "clamp_bwd"):
         if k in name:
             return k
     return name[:40]
 
 
 def main():
+    if sys.argv[1] == "--stats":                      # python tools/pmc_summary.py --stats <rocprofv3 -d dir> > kernel_stats.csv
+        w = csv.writer(sys.stdout)
+        w.writerow(["Name", "Calls", "TotalDurationUs", "AverageUs", "Percentage"])
+        for r in kernel_stats(sys.argv[2]):
+            w.writerow(r)
+        return
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
     out_json = sys.argv[sys.argv.index("--json") + 1] if "--json" in sys.argv else None
     prefix, workloads = args[0], [a for a in args[1:] if a != out_json]
