@@ -190,7 +190,7 @@ extern "C" int afr_plan_create(const afr_config* c, afr_plan** out) {
         if (ly.sk > 1) { ly.o_slab_w = carve((size_t)ly.sk * Pix * Kz * sizeof(float)); ly.o_slab_b = carve((size_t)ly.sk * Pix * sizeof(float)); }
         p->layers.push_back(ly);
         p->o_slab_e = carve((size_t)afr_sheet_blocks((int)B) * (size_t)p->s_wout * sizeof(float));
-        p->o_save = carve(B * (size_t)L * 40 * sizeof(float));
+        p->o_save = carve(B * (size_t)L * AFR_SHEET_SAVE_PER_POS * sizeof(float));
     } else if (c->kind == AFR_KIND_GLYPH) {
         if (c->n_hidden < 0 || c->n_hidden > AFR_MAX_HIDDEN) { delete p; return fail(AFR_EINVAL, "n_hidden out of range"); }
         if (E % 8) { delete p; return fail(AFR_EUNSUPPORTED, "embed_dim must be a multiple of 8"); }

@@ -182,13 +182,16 @@ hipError_t afr_launch_glyph_embed_bwd(int act_dtype, const void* d, const int64_
 
 // sheet front end (sheet.hip)
 struct SheetDims { int L, Lmax, E, H, F, vocab; };
+constexpr int AFR_SHEET_SAVE_PER_POS = 56;   // 32 + 4 + 4 + 16, see SheetDrop::save
 struct SheetParams {   // device pointers into the flat f32 parameter buffer
     const float *pos, *emb, *w_in, *b_in, *w_o, *b_o, *ln_g, *ln_b, *w1, *b1;
 };
 struct SheetDrop {
     uint32_t key_e, key_a, key_f, thr_e, thr_a, thr_f; float sc_e, sc_a, sc_f; int training;
-    // optional per-string save area written by a training forward and read by backward: [B][L*40] floats =
-    // attention output o [L][32], softmax row max [4][L], 1/row-sum [4][L]  (spares backward the attention recompute)
+    // optional per-string save area written by a training forward and read by backward: [B][L*AFR_SHEET_SAVE_PER_POS]
+    // words = attention output o [L][32], softmax row max [4][L], 1/row-sum [4][L], and the attention-dropout keep bits
+    // [4][L][4] (row (h,i), key j: bit (j>>1)&31 of word (j&1)*2 + (j>>6)).  Spares backward the attention recompute
+    // and both of its passes the per-element counter hash (3 quarter-rate integer multiplies per probability).
     float* save;
 };
 // offsets (in floats) of the 10 small tensors inside one partial-gradient slab == their flat-buffer offsets

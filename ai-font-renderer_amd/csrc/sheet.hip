@@ -38,11 +38,11 @@ constexpr int al4c(int n) { return (n + 3) & ~3; }
 constexpr int O_E = W_FLOATS, O_BIG = O_E + al4c(LMAX * SE), O_O = O_BIG + LMAX * SQ, O_XH = O_O + al4c(LMAX * SE),
               O_DN = O_XH + LMAX * SD, O_RSTD = O_DN + al4c(LMAX * SE), O_SMAX = O_RSTD + al4c(LMAX), O_SINV = O_SMAX + H * LMAX,
               O_SDEL = O_SINV + H * LMAX, O_REDA = O_SDEL + H * LMAX, O_REDB = O_REDA + 256, O_TOK = O_REDB + 256,
-              O_NXT = O_TOK + LMAX, BWD_FLOATS = O_NXT + LMAX;
-// forward: e | qkv | o | r | n | rstd | smax | sinv | tok
+              O_NXT = O_TOK + LMAX, O_MB = O_NXT + LMAX, BWD_FLOATS = O_MB + 4 * H * LMAX;
+// forward: e | qkv | o | r | n | rstd | smax | sinv | tok | attention keep bits
 constexpr int F_E = W_FLOATS, F_QKV = F_E + al4c(LMAX * SE), F_O = F_QKV + LMAX * SQ, F_R = F_O + al4c(LMAX * SE),
               F_N = F_R + al4c(LMAX * SE), F_RSTD = F_N + al4c(LMAX * SE), F_SMAX = F_RSTD + al4c(LMAX), F_SINV = F_SMAX + H * LMAX,
-              F_TOK = F_SINV + H * LMAX, FWD_FLOATS = F_TOK + LMAX;
+              F_TOK = F_SINV + H * LMAX, F_MB = F_TOK + LMAX, FWD_FLOATS = F_MB + 4 * H * LMAX;
 static_assert(BWD_FLOATS * 4 <= 160 * 1024 && FWD_FLOATS * 4 <= 160 * 1024, "one string's state must fit the CU's LDS");
 
 struct Wts { float *Win, *bin, *Wo, *bo, *lg, *lb, *W1, *b1; };
@@ -142,8 +142,11 @@ __device__ __forceinline__ float attn_mask(const SheetDrop& dr, int b, int h, in
     return afr_keep(idx, dr.key_a, dr.thr_a) ? dr.sc_a : 0.f;
 }
 // o = concat_h( dropout(softmax((q/sqrt(D)) k^T)) v )      two adjacent lanes per (head, query row), keys split even/odd
+// mbits (optional, training only): the dropout keep decisions, one bit per probability, stored as the lanes produce
+// them: row (h,i), key j = 2t + part -> bit t&31 of mbits[((h*L+i)*2 + part)*2 + (t>>5)].  The backward passes read
+// the bit instead of hashing the element's counter again.
 __device__ __forceinline__ void ph_attention(float* o, const float* qkv, const SheetDrop& dr, int b, int L, int tid,
-                                             float* smax_out = nullptr, float* sinv_out = nullptr) {
+                                             float* smax_out = nullptr, float* sinv_out = nullptr, uint32_t* mbits = nullptr) {
     const float scale = 0.35355339059327373f;    // sqrt(1/8), applied to q as torch does
     for (int rr = tid; rr < 2 * H * L; rr += NT) {
         const int r = rr >> 1, part = rr & 1;
@@ -162,16 +165,29 @@ __device__ __forceinline__ void ph_attention(float* o, const float* qkv, const S
         float sum = 0.f, acc[D];
 #pragma unroll
         for (int d = 0; d < D; ++d) acc[d] = 0.f;
-#pragma clang loop unroll_count(2) vectorize(disable) interleave(disable)
-        for (int j = part; j < L; j += 2) {
-            ld8(qkv + j * SQ + E + h * D, kv);
-            const float p = __expf(dot8(q, kv) - mx);
-            sum += p;
-            const float pm = p * attn_mask(dr, b, h, i, j, L);
-            ld8(qkv + j * SQ + 2 * E + h * D, kv);
+        // keep bits of this lane's keys (j = 2t + part): bit t&31 of wb[t>>5].  Two plain loops (keys below / from 64) so
+        // that each unrolls by two like the loop without the bits; no cross-lane operation inside them.
+        uint32_t wb[2] = {0u, 0u};
 #pragma unroll
-            for (int d = 0; d < D; ++d) acc[d] = fmaf(pm, kv[d], acc[d]);
+        for (int half = 0; half < 2; ++half) {
+            uint32_t bit = 1u, acc_bits = 0u;
+            const int jend = half ? L : min(L, 64);
+#pragma clang loop unroll_count(2) vectorize(disable) interleave(disable)
+            for (int j = 64 * half + part; j < jend; j += 2) {
+                ld8(qkv + j * SQ + E + h * D, kv);
+                const float p = __expf(dot8(q, kv) - mx);
+                sum += p;
+                const float am = attn_mask(dr, b, h, i, j, L);
+                acc_bits |= am != 0.f ? bit : 0u;
+                bit <<= 1;
+                const float pm = p * am;
+                ld8(qkv + j * SQ + 2 * E + h * D, kv);
+#pragma unroll
+                for (int d = 0; d < D; ++d) acc[d] = fmaf(pm, kv[d], acc[d]);
+            }
+            wb[half] = acc_bits;
         }
+        if (mbits) *reinterpret_cast<uint2*>(mbits + rr * 2) = make_uint2(wb[0], wb[1]);
         sum += __shfl_xor(sum, 1, 64);
         const float inv = 1.f / sum;
         if (smax_out && part == 0) { smax_out[r] = mx; sinv_out[r] = inv; }
@@ -232,6 +248,7 @@ __global__ __launch_bounds__(NT) void sheet_fwd_kernel(SheetDims dm, SheetParams
     float* const smax = sm + F_SMAX;   // [4L]
     float* const sinv = sm + F_SINV;   // [4L]
     int* const tok = reinterpret_cast<int*>(sm + F_TOK);
+    uint32_t* const mb = reinterpret_cast<uint32_t*>(sm + F_MB);   // [4L][4] attention-dropout keep bits
     load_weights(w, P, tid0);
     const size_t Kz = (size_t)dm.Lmax * F;
     for (int b = blockIdx.x; b < B; b += gridDim.x) {
@@ -243,12 +260,14 @@ __global__ __launch_bounds__(NT) void sheet_fwd_kernel(SheetDims dm, SheetParams
         __syncthreads();
         ph_inproj(qkv, e, w, L, tid);
         __syncthreads();
-        ph_attention(o, qkv, dr, b, L, tid, dr.save ? smax : nullptr, sinv);
+        ph_attention(o, qkv, dr, b, L, tid, dr.save ? smax : nullptr, sinv, (dr.save && dr.training) ? mb : nullptr);
         __syncthreads();
         if (dr.save) {                                              // keep o and the softmax statistics for backward
-            float* sv = dr.save + (size_t)b * L * 40;
+            float* sv = dr.save + (size_t)b * L * AFR_SHEET_SAVE_PER_POS;
             for (int i = tid; i < L * E; i += NT) sv[i] = o[(i >> 5) * SE + (i & 31)];
             for (int i = tid; i < H * L; i += NT) { sv[L * E + i] = smax[i]; sv[L * E + H * L + i] = sinv[i]; }
+            if (dr.training)
+                for (int i = tid; i < 4 * H * L; i += NT) reinterpret_cast<uint32_t*>(sv)[L * 40 + i] = mb[i];
         }
         ph_outproj_res(r, e, o, w, L, tid);
         __syncthreads();
@@ -313,6 +332,7 @@ __global__ __launch_bounds__(NT) void sheet_bwd_kernel(SheetDims dm, SheetParams
     int* const tok = reinterpret_cast<int*>(sm + O_TOK);   // [L]
     int* const nxt = reinterpret_cast<int*>(sm + O_NXT);   // [L] occurrence chain: low 16 bits = 1 + next position with the
                                        //     same code (0: none), bit 16 = this is the code's first occurrence in the string
+    uint32_t* const mb = reinterpret_cast<uint32_t*>(sm + O_MB);   // [4L][4] attention-dropout keep bits (from the forward)
     float* const nbuf = big;               // n  [L][33]
     float* const df = big + LMAX * SE;     // df [L][64]
     load_weights(w, P, tid0);
@@ -326,6 +346,7 @@ __global__ __launch_bounds__(NT) void sheet_bwd_kernel(SheetDims dm, SheetParams
 #pragma unroll
     for (int k = 0; k < KPOS; ++k) aPos[k] = 0.f;
     const float scale = 0.35355339059327373f;
+    const float keep_sc = dr.training ? dr.sc_a : 1.f;      // value of a kept attention probability's dropout mask
     const size_t Kz = (size_t)dm.Lmax * F;
     float* Sblk = slabs + (size_t)blockIdx.x * so.total;       // this block's partial slab
     // The block zeroes its own slab (55 KB, L2): the embedding rows are accumulated into it string by string, rows of dP
@@ -348,9 +369,11 @@ __global__ __launch_bounds__(NT) void sheet_bwd_kernel(SheetDims dm, SheetParams
         // ---- codes, then the embedded string; o and the softmax statistics come from the training forward
         ph_tokens(tok, x, ldx, b, L, dm.vocab, nullptr, tid);
         if (saved) {
-            const float* sv = dr.save + (size_t)b * L * 40;
+            const float* sv = dr.save + (size_t)b * L * AFR_SHEET_SAVE_PER_POS;
             for (int i = tid; i < L * E; i += NT) o[(i >> 5) * SE + (i & 31)] = sv[i];
             for (int i = tid; i < H * L; i += NT) { smax[i] = sv[L * E + i]; sinv[i] = sv[L * E + H * L + i]; }
+            if (dr.training)
+                for (int i = tid; i < 4 * H * L; i += NT) mb[i] = reinterpret_cast<const uint32_t*>(sv)[L * 40 + i];
         }
         __syncthreads();
         ph_embed(e, tok, P, dr, b, L, tid);
@@ -370,7 +393,7 @@ __global__ __launch_bounds__(NT) void sheet_bwd_kernel(SheetDims dm, SheetParams
         if (!saved) {                                              // no training forward ran: recompute o and the statistics
             ph_inproj(big, e, w, L, tid);
             __syncthreads();
-            ph_attention(o, big, dr, b, L, tid, smax, sinv);
+            ph_attention(o, big, dr, b, L, tid, smax, sinv, dr.training ? mb : nullptr);
             __syncthreads();
         }
         TMARK(0);
@@ -442,16 +465,23 @@ __global__ __launch_bounds__(NT) void sheet_bwd_kernel(SheetDims dm, SheetParams
             float sum = 0.f, num = 0.f, t1[D], t2[D];
 #pragma unroll
             for (int d = 0; d < D; ++d) { t1[d] = 0.f; t2[d] = 0.f; }
-#pragma clang loop unroll_count(2) vectorize(disable) interleave(disable)
-            for (int j = part; j < L; j += 2) {
-                ld8(big + j * SQ + E + h * D, kk);
-                ld8(big + j * SQ + 2 * E + h * D, vv);
-                const float p = __expf(dot8(q, kk) - mx);
-                const float pa = p * (dot8(dO, vv) * attn_mask(dr, b, h, i, j, L));
-                sum += p;
-                num += pa;
+            const uint2 mw = dr.training ? *reinterpret_cast<const uint2*>(mb + rr * 2) : make_uint2(~0u, ~0u);   // this lane's keys
 #pragma unroll
-                for (int d = 0; d < D; ++d) { t1[d] = fmaf(pa, kk[d], t1[d]); t2[d] = fmaf(p, kk[d], t2[d]); }
+            for (int half = 0; half < 2; ++half) {      // keys below / from 64: one word of keep bits each
+                uint32_t bits = half ? mw.y : mw.x;
+                const int jend = half ? L : min(L, 64);
+#pragma clang loop unroll_count(2) vectorize(disable) interleave(disable)
+                for (int j = 64 * half + part; j < jend; j += 2) {
+                    ld8(big + j * SQ + E + h * D, kk);
+                    ld8(big + j * SQ + 2 * E + h * D, vv);
+                    const float p = __expf(dot8(q, kk) - mx);
+                    const float pa = p * (dot8(dO, vv) * ((bits & 1u) ? keep_sc : 0.f));
+                    bits >>= 1;
+                    sum += p;
+                    num += pa;
+#pragma unroll
+                    for (int d = 0; d < D; ++d) { t1[d] = fmaf(pa, kk[d], t1[d]); t2[d] = fmaf(p, kk[d], t2[d]); }
+                }
             }
             sum += __shfl_xor(sum, 1, 64);
             num += __shfl_xor(num, 1, 64);
@@ -474,6 +504,7 @@ __global__ __launch_bounds__(NT) void sheet_bwd_kernel(SheetDims dm, SheetParams
             float kk[D], vv[D], dk[D], dv[D], qs[D], dO[D];
             ld8(big + j * SQ + E + h * D, kk);
             ld8(big + j * SQ + 2 * E + h * D, vv);
+            const int mword = (j & 1) * 2 + (j >> 6), mbit = (j >> 1) & 31;     // where key j's keep bit sits in a row's 4 words
 #pragma unroll
             for (int d = 0; d < D; ++d) { dk[d] = 0.f; dv[d] = 0.f; }
 #pragma clang loop unroll_count(2) vectorize(disable) interleave(disable)
@@ -483,7 +514,8 @@ __global__ __launch_bounds__(NT) void sheet_bwd_kernel(SheetDims dm, SheetParams
 #pragma unroll
                 for (int d = 0; d < D; ++d) qs[d] *= scale;
                 const float p = __expf(dot8(qs, kk) - smax[h * L + i]) * sinv[h * L + i];
-                const float m = attn_mask(dr, b, h, i, j, L);
+                const uint32_t bits = dr.training ? mb[(h * L + i) * 4 + mword] : 0xffffffffu;
+                const float m = ((bits >> mbit) & 1u) ? keep_sc : 0.f;
                 const float dS = p * (dot8(dO, vv) * m - sdel[h * L + i]);
                 const float pm = p * m;
 #pragma unroll

@@ -150,7 +150,7 @@ def measure(name, dtype, B, K, W, rank, world, dist, with_roofline=True):
     from ai_font_renderer_amd.engine import Engine
     from ai_font_renderer_amd.parallel import DataParallelStepper
     cfg = WORKLOADS[name]["cfg"]
-    eng = Engine(cfg, dtype=dtype, max_batch=B, rank=rank)
+    eng = Engine(cfg, dtype=dtype, max_batch=B, rank=rank, flags=int(os.environ.get("AFR_ENGINE_FLAGS", "0")))   # kernel A/B runs
     eng.load_params(synth.make_params(cfg))                           # same formula-generated weights on every rank
     x, font, tgt = make_inputs(name, cfg, B, rank)
     x, tgt = x.cuda(), tgt.cuda()
