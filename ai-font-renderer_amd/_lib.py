@@ -58,6 +58,8 @@ SIGNATURES = {
     "afr_profile_dump": (_i32, [_vp, C.c_char_p, _i32]),
     "afr_debug_copy": (_i32, [_vp, _i32, _vp, _sz, C.POINTER(_sz), _vp]),
     "afr_op_gemm": (_i32, [_i32, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "afr_op_gemm_fix_workspace_bytes": (_sz, [_i32, _i32, _i32, _i32]),
+    "afr_op_gemm_fix": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _sz, _vp]),
     "afr_op_reduce": (_i32, [_vp, _vp, _i32, _i64, _i64, _f32, _i32, _vp]),
     "afr_op_reduce_group": (_i32, [_i32, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_i32), C.POINTER(_i64), C.POINTER(_i64), _vp]),
     "afr_op_adamw": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _i64, _f32, _vp]),

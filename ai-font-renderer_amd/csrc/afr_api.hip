@@ -83,6 +83,7 @@ struct afr_plan {
     bool fused1 = false;
     bool wT_valid = false;         // bf16: the transposed operand copies W1T / W2T match the current parameters
     size_t o_w1t = 0, o_w2t = 0, o_slab1 = 0;
+    size_t o_fix = 0, o_fixcnt = 0; bool have_fix = false;   // in-launch split-K: slice parking area + per-tile arrival counters
     // glyph layer table
     struct Layer { int N, K; int64_t w_off, b_off; int sk = 1; size_t o_slab_w = 0, o_slab_b = 0; };
     std::vector<Layer> layers;
@@ -191,6 +192,12 @@ extern "C" int afr_plan_create(const afr_config* c, afr_plan** out) {
         p->layers.push_back(ly);
         p->o_slab_e = carve((size_t)afr_sheet_blocks((int)B) * (size_t)p->s_wout * sizeof(float));
         p->o_save = carve(B * (size_t)L * AFR_SHEET_SAVE_PER_POS * sizeof(float));
+        if (c->dtype == AFR_BF16 && (c->reserved & 8)) {   // opt-in: fc_output's input-gradient product as in-launch split-K
+            int hd, sk;
+            if (afr_gemm_fix_plan((int)B, Pix, (int)Kz, &hd, &sk) || afr_gemm_fix_plan((int)B, (int)Kz, Pix, &hd, &sk)) {
+                p->o_fix = carve(AFR_FIX_WS_BYTES); p->o_fixcnt = carve(AFR_FIX_MAX_SLICES * sizeof(unsigned)); p->have_fix = true;
+            }
+        }
     } else if (c->kind == AFR_KIND_GLYPH) {
         if (c->n_hidden < 0 || c->n_hidden > AFR_MAX_HIDDEN) { delete p; return fail(AFR_EINVAL, "n_hidden out of range"); }
         if (E % 8) { delete p; return fail(AFR_EUNSUPPORTED, "embed_dim must be a multiple of 8"); }
@@ -318,6 +325,10 @@ extern "C" int afr_bind(afr_plan* p, float* params, float* grads, float* m, floa
     p->ws = (char*)ws; p->ws_bytes = ws_bytes;
     p->have_du = false;
     p->wT_valid = false;
+    if (p->have_fix) {                                   // arrival counters start at zero; the kernels re-arm them
+        DevGuard dg(dev);
+        HIPCHK(hipMemset(p->ws + p->o_fixcnt, 0, AFR_FIX_MAX_SLICES * sizeof(unsigned)));
+    }
     return AFR_OK;
 }
 
@@ -483,8 +494,18 @@ static int run_gemm(afr_plan* p, hipStream_t s, int flags, const void* A, const 
     // algorithmic output); with the fused optimizer the output is p,m,v read + p,m,v(,shadow) written
     const double out_bytes = fa ? (double)M * N * (24.0 + (fa->shadow ? 2.0 : 0.0)) : (splitk > 1 ? 4.0 : ob) * (double)M * N;
     char tag[96];
-    snprintf(tag, sizeof tag, "%s[%dx%dx%d]", afr_gemm_kernel_name(p->cfg.dtype, g), M, N, K);
     const double fl_ = 2.0 * M * (double)N * K, by_ = eb * ((double)M * K + (double)N * K) + out_bytes;
+    int hd = 0, fsk = 1;
+    if (p->have_fix && p->cfg.dtype == AFR_BF16 && splitk == 1 && !fl && !fa && !colsum && (p->cfg.reserved & 8) &&
+        afr_gemm_fix_plan(M, N, K, &hd, &fsk)) {
+        g.head_tiles = hd; g.splitk = fsk;
+        g.fix_ws = (float*)(p->ws + p->o_fix); g.fix_cnt = (unsigned*)(p->ws + p->o_fixcnt);
+        snprintf(tag, sizeof tag, "gemm_bf16_group256[%dx%dx%d]", M, N, K);
+        ProfScope ps(p, s, tag, fl_, by_);
+        HIPCHK(afr_launch_gemm_fix(g, s));
+        return AFR_OK;
+    }
+    snprintf(tag, sizeof tag, "%s[%dx%dx%d]", afr_gemm_kernel_name(p->cfg.dtype, g), M, N, K);
     if (p->defer && afr_gemm_groupable(p->cfg.dtype, g) && p->pend.size() < 4) {
         p->pend.push_back(g); p->pend_tag.push_back(tag); p->pend_flops += fl_; p->pend_bytes += by_;
         return AFR_OK;
@@ -1083,6 +1104,36 @@ extern "C" int afr_op_gemm(int dtype, int flags, const void* A, const void* B, v
     g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldaux = ldaux; g.flags = flags; g.splitk = splitk;
     g.slab_stride = (long long)M * ldc;
     HIPCHK(afr_launch_gemm(dtype, g, (hipStream_t)stream));
+    return AFR_OK;
+}
+extern "C" size_t afr_op_gemm_fix_workspace_bytes(int M, int N, int head_tiles, int splitk) {
+    const long long tiles = (long long)((M + 255) / 256) * ((N + 255) / 256);
+    const long long tail = tiles - (head_tiles < tiles ? (head_tiles < 0 ? 0 : head_tiles) : tiles);
+    return (size_t)(tail * splitk) * AFR_FIX_SLICE_BYTES + (size_t)(tail > 0 ? tail : 1) * sizeof(unsigned);
+}
+extern "C" int afr_op_gemm_fix(int flags, const void* A, const void* B, void* C, const float* bias, const void* aux,
+                               int M, int N, int K, int lda, int ldb, int ldc, int ldaux, int head_tiles, int splitk,
+                               void* workspace, size_t workspace_bytes, void* stream) {
+    if (!A || !B || !C || !workspace) return fail(AFR_EINVAL, "null operand");
+    if (M <= 0 || N <= 0 || K <= 0 || splitk < 1 || splitk > 64 || head_tiles < 0) return fail(AFR_EINVAL, "bad GEMM extents");
+    const bool ak = flags & AFR_GEMM_A_KSTRIDED, bk = flags & AFR_GEMM_B_KSTRIDED;
+    if ((ak ? M : K) % 8 || (bk ? N : K) % 8 || lda % 8 || ldb % 8 || N % 8 || ldc % 8)
+        return fail(AFR_EUNSUPPORTED, "contiguous extents and leading dimensions must be multiples of 8");
+    const long long ea = (long long)(ak ? K : M) * lda * 2, ebb = (long long)(bk ? K : N) * ldb * 2;
+    if (ea >= (1ll << 31) || ebb >= (1ll << 31))
+        return fail(AFR_EUNSUPPORTED, "a bf16 GEMM operand must be smaller than 2 GiB (A %lld bytes, B %lld bytes)", ea, ebb);
+    const size_t need = afr_op_gemm_fix_workspace_bytes(M, N, head_tiles, splitk);
+    if (workspace_bytes < need || ((uintptr_t)workspace & 15)) return fail(AFR_EINVAL, "workspace too small or misaligned: %zu < %zu", workspace_bytes, need);
+    const long long tiles = (long long)((M + 255) / 256) * ((N + 255) / 256);
+    const long long tail = tiles - (head_tiles < tiles ? head_tiles : tiles);
+    DevGuard dg(device_of(C));
+    GemmParams g;
+    g.A = A; g.B = B; g.C = C; g.bias = bias; g.aux = aux; g.M = M; g.N = N; g.K = K;
+    g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldaux = ldaux; g.flags = flags; g.splitk = splitk;
+    g.head_tiles = head_tiles;
+    g.fix_ws = (float*)workspace;
+    g.fix_cnt = (unsigned*)((char*)workspace + (size_t)(tail * splitk) * AFR_FIX_SLICE_BYTES);
+    HIPCHK(afr_launch_gemm_fix(g, (hipStream_t)stream));
     return AFR_OK;
 }
 extern "C" int afr_op_reduce(float* dst, const float* slabs, int nslabs, int64_t stride, int64_t n, float scale, int acc,

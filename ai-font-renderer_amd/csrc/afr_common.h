@@ -113,6 +113,11 @@ struct GemmParams {
     // the epilogue applies AdamW to the matching tile of p/m/v (same [M][ldc] layout) and refreshes the bf16 shadow
     float* ad_p = nullptr; float* ad_m = nullptr; float* ad_v = nullptr; bf16_t* ad_shadow = nullptr;
     float ad_decay = 1.f, ad_b1 = 0.f, ad_b2 = 0.f, ad_eps = 0.f, ad_step = 0.f, ad_rsqrt_bc2 = 1.f;
+    // optional in-launch split-K (bf16, 256x256 tiles; gemm.hip gemm_bf16_256_body): the first head_tiles tiles of the
+    // walk are computed whole, each remaining tile as `splitk` K-slices parked in fix_ws (256 KiB per slice) and summed in
+    // slice order by the slice block that arrives last (fix_cnt: one zeroed counter per tail tile, re-armed by the kernel).
+    // The output then takes the full epilogue (bias / ReLU / mask / bf16), unlike plain split-K's f32 partial slabs.
+    int head_tiles = 0; float* fix_ws = nullptr; unsigned* fix_cnt = nullptr;
 };
 // torch.optim.AdamW element update (reference model.py:273,310); shared by adamw_kernel and the fused GEMM epilogue
 __device__ __forceinline__ void adamw_elem(float& p, float& m, float& v, float g, float decay, float b1, float b2,
@@ -128,6 +133,11 @@ hipError_t afr_launch_gemm(int dtype, const GemmParams& p, hipStream_t s);
 bool afr_gemm_groupable(int dtype, const GemmParams& p);
 hipError_t afr_launch_gemm_group(int dtype, const GemmParams* ps, int n, int tile256, hipStream_t s);
 void afr_gemm_pair_plan(int B, int n_out, int k_in, int* tile256, int* splitk);
+// in-launch split-K plan for one bf16 product on 256x256 tiles: true when it beats the ring kernels by the launch model;
+// workspace need is (tiles - head_tiles) * splitk * AFR_FIX_SLICE_BYTES, never more than AFR_FIX_WS_BYTES
+constexpr size_t AFR_FIX_SLICE_BYTES = 256 * 256 * 4, AFR_FIX_MAX_SLICES = 256, AFR_FIX_WS_BYTES = AFR_FIX_SLICE_BYTES * AFR_FIX_MAX_SLICES;
+bool afr_gemm_fix_plan(int M, int N, int K, int* head_tiles, int* splitk);
+hipError_t afr_launch_gemm_fix(const GemmParams& p, hipStream_t s);
 const char* afr_gemm_kernel_name(int dtype, const GemmParams& p);
 
 hipError_t afr_launch_reduce(float* dst, const float* slabs, int nslabs, long long slab_stride, long long n,

@@ -27,13 +27,15 @@
 // indices... i.e. the 8 big-operand tiles of a group stay hot while the small operand is swept once per GROUP rather
 // than once per slow index (R0's dW GEMM re-read its 13 MB activation operand 75x, 1 GB of extra HBM reads per step,
 // before this).  Placement changes speed only, never results.
-__device__ __forceinline__ void tile_of_block(const GemmParams& p, int BM, int BN, int b, int nb, int& tm, int& tn, int& z) {
+// block -> position in its XCD's contiguous range of the walk (blocks b, b+8, ... share an XCD)
+__device__ __forceinline__ int xcd_walk(int b, int nb) {
     const int q = nb >> 3, r = nb & 7, xcd = b & 7, idx = b >> 3;
-    const int v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+// walk position t (0 .. tiles-1) -> tile coordinates; q, r describe the XCD ranges the walk is cut into (nb / 8, nb % 8)
+__device__ __forceinline__ void tile_coords(const GemmParams& p, int BM, int BN, int t, int q, int r, int& tm, int& tn) {
     const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
     const int tiles = tiles_m * tiles_n;
-    z = v / tiles;
-    const int t = v - z * tiles;
     const bool n_slow = p.N > p.M;                   // the slow (grouped) dimension is the larger operand's
     const int ts = n_slow ? tiles_n : tiles_m, tf = n_slow ? tiles_m : tiles_n;
     // 8 slow tiles per group, or fewer when that makes an XCD's contiguous range exactly one group: then the group's
@@ -48,6 +50,12 @@ __device__ __forceinline__ void tile_of_block(const GemmParams& p, int BM, int B
     const int sidx = s0 + rr % gs, fidx = rr / gs;
     tm = n_slow ? fidx : sidx;
     tn = n_slow ? sidx : fidx;
+}
+__device__ __forceinline__ void tile_of_block(const GemmParams& p, int BM, int BN, int b, int nb, int& tm, int& tn, int& z) {
+    const int v = xcd_walk(b, nb);
+    const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+    z = v / tiles;
+    tile_coords(p, BM, BN, v - z * tiles, nb >> 3, nb & 7, tm, tn);
 }
 
 // ------------------------------------------------------------------------------------------- f32
@@ -836,11 +844,34 @@ __device__ __forceinline__ void gemm_bf16_256_body(const GemmParams& p, const in
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
-    int tm, tn, z;
-    tile_of_block(p, BM, BNN, bid, nblk, tm, tn, z);
-    if (z >= p.splitk) return;
+    int tm, tn, z, ksplit = p.splitk;
+    int tail_idx = -1;                                  // >= 0: a K-slice of tail tile tail_idx, reduced in-kernel (fix_ws)
+    if (p.fix_ws) {
+        // Split-K with the reduction INSIDE the launch: the first head_tiles tiles of the walk are computed whole by one
+        // block each (typically the full rounds of the chip); each remaining ("tail") tile is cut into splitk K-slices so
+        // that the last, partial round is spread over all CUs.  A slice block parks its accumulators in fix_ws (a private
+        // register-image layout: every store and load is a whole 1 KiB wave access) and takes a ticket; the block that
+        // draws the tile's last ticket adds the slices in slice order -- whoever that block is, so results do not depend
+        // on arrival order -- and runs the normal epilogue (bias / ReLU / mask / bf16).  Nobody waits for anybody.
+        const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BNN - 1) / BNN);
+        const int head = min(p.head_tiles, tiles), ntail = tiles - head;
+        int t;
+        if (bid < head) { t = xcd_walk(bid, head); z = 0; ksplit = 1; }
+        else {
+            const int b2 = bid - head, nb2 = ntail * p.splitk;
+            if (b2 >= nb2) return;
+            const int v2 = xcd_walk(b2, nb2);
+            z = v2 / ntail;
+            tail_idx = v2 - z * ntail;
+            t = head + tail_idx;
+        }
+        tile_coords(p, BM, BNN, t, tiles >> 3, tiles & 7, tm, tn);
+    } else {
+        tile_of_block(p, BM, BNN, bid, nblk, tm, tn, z);
+        if (z >= p.splitk) return;
+    }
     const int m0 = tm * BM, n0 = tn * BNN;
-    const int klen = ((p.K + p.splitk - 1) / p.splitk + BK - 1) / BK * BK;
+    const int klen = ((p.K + ksplit - 1) / ksplit + BK - 1) / BK * BK;
     const int kbeg = z * klen;
     const int kend = min(p.K, kbeg + klen);
     const int nt = (kend > kbeg) ? (kend - kbeg + BK - 1) / BK : 0;
@@ -998,6 +1029,38 @@ __device__ __forceinline__ void gemm_bf16_256_body(const GemmParams& p, const in
         }
         __syncthreads();
     }
+    if (tail_idx >= 0) {
+        // park this K-slice, take a ticket; only the tile's last arrival goes on (see the mapping above)
+        f32x4* ws = reinterpret_cast<f32x4*>(p.fix_ws) + ((size_t)tail_idx * p.splitk * 8 + wave) * 2048 + lane;
+        {
+            f32x4* mine = ws + (size_t)z * 8 * 2048;
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) mine[(i * 4 + j) * 64] = acc[i][j];
+        }
+        __threadfence();                                 // every wave: its stores are visible device-wide before the ticket
+        __syncthreads();
+        unsigned* flag = reinterpret_cast<unsigned*>(smem);
+        if (tid == 0) *flag = atomicAdd(p.fix_cnt + tail_idx, 1u);
+        __syncthreads();
+        const unsigned ticket = *reinterpret_cast<volatile unsigned*>(flag);
+        __syncthreads();                                 // the flag word is part of wave 0's epilogue staging area
+        if (ticket != (unsigned)p.splitk - 1u) return;
+        __threadfence();                                 // acquire: the other slices' stores (other CUs, other XCDs' L2s)
+        if (tid == 0) p.fix_cnt[tail_idx] = 0u;          // re-armed for the next launch (everyone has arrived)
+        for (int zz = 0; zz < p.splitk; ++zz) {
+            const f32x4* src = ws + (size_t)zz * 8 * 2048;
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const f32x4 v = src[(i * 4 + j) * 64];
+                    acc[i][j] = zz == 0 ? v : acc[i][j] + v;
+                }
+        }
+        z = 0;
+    }
     // two passes of the 64x64 wave epilogue: accumulator rows 0..3 (tile rows wr*128 .. +63), then 4..7
     float lsum = 0.f;
     float* Wt = reinterpret_cast<float*>(smem) + wave * 4096;
@@ -1112,6 +1175,43 @@ void afr_gemm_pair_plan(int B, int n_out, int k_in, int* tile256, int* splitk) {
     if (sk < 1) sk = 1;
     if (B / sk < 256) sk = 0;                                         // 0: no grouped launch
     *splitk = sk;
+}
+// In-launch split-K on 256x256 tiles (GemmParams::fix_ws): worth it when the tile count leaves the last round of the chip
+// mostly empty -- the tail tiles are then cut along K so that the round's work is spread over every CU -- and the product
+// is deep enough that the 256x256 kernel's fewer staged bytes per FLOP outweigh the parked slices.  Launch model in
+// microseconds per K-tile (measured, operands in L2/MALL): 1.5 per block-round of the 256x256 kernel, 0.92 of the 256x128
+// ring, 0.95 of the 128x128 kernel at two blocks per CU; 12 us for parking and summing the slices.
+bool afr_gemm_fix_plan(int M, int N, int K, int* head_tiles, int* splitk) {
+    static const int force = getenv("AFR_GEMM_FIX") ? atoi(getenv("AFR_GEMM_FIX")) : -1;     // 0 | 1: kernel A/B measurements
+    if (force == 0 || M < 256 || N < 256 || K < 2048) return false;
+    const int kt = (K + 63) / 64;
+    const int tiles = ((M + 255) / 256) * ((N + 255) / 256);
+    const int rounds = tiles / 256, rem = tiles % 256;
+    int sk = 1;
+    if (rem) {
+        sk = 256 / rem;
+        if (sk > 8) sk = 8;
+        while (sk > 1 && kt / sk < 8) --sk;
+    }
+    if (getenv("AFR_GEMM_FIX_SK") && rem) sk = atoi(getenv("AFR_GEMM_FIX_SK"));            // kernel A/B measurements
+    if ((size_t)rem * sk > AFR_FIX_MAX_SLICES) return false;
+    const double c256 = (rounds * (double)kt + (rem ? (kt + sk - 1) / sk : 0)) * 1.5 + (sk > 1 ? 12.0 : 0.0);
+    const long long tw = (long long)((M + 255) / 256) * ((N + 127) / 128), tn = (long long)((M + 127) / 128) * ((N + 127) / 128);
+    const double cw = (double)((tw + 255) / 256) * kt * 0.92, cn = (double)((tn + 511) / 512) * kt * 0.95;
+    const double cr = cw < cn ? cw : cn;
+    if (force != 1 && !(c256 < 0.9 * cr)) return false;
+    *head_tiles = tiles - rem;
+    *splitk = sk;
+    return true;
+}
+hipError_t afr_launch_gemm_fix(const GemmParams& p, hipStream_t s) {
+    const int tiles = ((p.M + 255) / 256) * ((p.N + 255) / 256);
+    const int head = p.head_tiles < tiles ? p.head_tiles : tiles;
+    bf16k::GemmGroup g;
+    g.n = 1; g.p[0] = p; g.blk0[0] = 0;
+    g.blk0[1] = head + (tiles - head) * p.splitk;
+    hipLaunchKernelGGL(bf16k::gemm_bf16_group256, dim3(g.blk0[1]), dim3(512), 0, s, g);
+    return hipGetLastError();
 }
 hipError_t afr_launch_gemm_group(int dtype, const GemmParams* ps, int n, int tile256, hipStream_t s) {
     if (n <= 0) return hipSuccess;

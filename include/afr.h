@@ -60,7 +60,9 @@ typedef struct afr_config {
                             weight-gradient GEMM and its gradient never reaches HBM)
                             bit 1: one launch per product in backward (no grouped dW+dX launches): A/B measurements
                             bit 2: small one-hidden-layer glyph nets through the generic per-layer kernels instead of
-                            the fused whole-step kernel of afr_train_step (A/B measurements, parity cross-checks)         */
+                            the fused whole-step kernel of afr_train_step (A/B measurements, parity cross-checks)
+                            bit 3: OPT IN to in-launch split-K (afr_op_gemm_fix) for the sheet model's fc_output products
+                            that have no fused loss / optimizer tail (today: the input gradient)                        */
 } afr_config;
 
 typedef struct afr_plan afr_plan;
@@ -170,6 +172,21 @@ enum { AFR_GEMM_BIAS = 1, AFR_GEMM_RELU = 2, AFR_GEMM_RELU_MASK = 4, AFR_GEMM_OU
 int afr_op_gemm(int dtype, int flags, const void* A, const void* B, void* C, const float* bias,
                 const void* aux, int M, int N, int K, int lda, int ldb, int ldc, int ldaux,
                 int splitk, void* stream);
+
+/* The same product (bf16 operands, any AFR_GEMM_* epilogue) as split-K WITH the reduction inside the launch, on
+ * 256x256 output tiles: the first head_tiles tiles of the kernel's walk are computed whole by one workgroup each, every
+ * remaining tile as `splitk` K-slices that are parked in `workspace` and added, in slice order, by whichever slice
+ * workgroup arrives last, which then runs the epilogue.  For products whose tile count leaves the chip's last round
+ * mostly empty (the sheet model's fc_output forward: 300 tiles = one full round of 256 + 44 tiles cut 5 ways; its input
+ * gradient: 100 tiles cut 2 ways).  Measured on R0's input gradient (1024 x 6400 x 19200): 220 us against the 128x128
+ * kernel's 276 us with the weight operand warm in the infinity cache, but 343 us against 281 us inside a training step,
+ * where the 246 MB weight shadow streams from HBM and one 160-KiB workgroup per CU hides that latency worse than two
+ * 64-KiB ones -- so afr_train_step uses it only when config.reserved bit 3 asks for it.  workspace: afr_op_gemm_fix_workspace_bytes() bytes, 16-byte
+ * aligned, whose trailing counter words (one per tail tile) are ZERO before the first call; the kernel leaves them zero. */
+size_t afr_op_gemm_fix_workspace_bytes(int M, int N, int head_tiles, int splitk);
+int afr_op_gemm_fix(int flags, const void* A, const void* B, void* C, const float* bias, const void* aux,
+                    int M, int N, int K, int lda, int ldb, int ldc, int ldaux, int head_tiles, int splitk,
+                    void* workspace, size_t workspace_bytes, void* stream);
 int afr_op_reduce(float* dst, const float* slabs, int nslabs, int64_t slab_stride, int64_t n,
                   float scale, int accumulate, void* stream);
 /* Several slab reductions in ONE launch (what a backward pass uses for all its split-K / per-block partial gradients):

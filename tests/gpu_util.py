@@ -58,3 +58,39 @@ def gemm(dtype, A_log, B_log, a_kstrided=False, b_kstrided=False, bias=None, rel
         return out.cpu()
     torch.cuda.synchronize()
     return Cd[0].float().cpu()
+
+
+def gemm_fix(A_log, B_log, head_tiles, splitk, a_kstrided=False, b_kstrided=False, bias=None, relu=False, aux=None, out_bf16=False,
+             repeats=1):
+    """The same product through afr_op_gemm_fix (bf16, 256x256 tiles, split-K reduced inside the launch).  Returns the
+    float32 CPU result(s) of `repeats` launches on one workspace and the workspace's counter words after the last one."""
+    lib = _lib.lib()
+    M, K = A_log.shape
+    N = B_log.shape[0]
+    A = dev(A_log.t().contiguous() if a_kstrided else A_log, torch.bfloat16)
+    B = dev(B_log.t().contiguous() if b_kstrided else B_log, torch.bfloat16)
+    flags = (_lib.GEMM_A_KSTRIDED if a_kstrided else 0) | (_lib.GEMM_B_KSTRIDED if b_kstrided else 0)
+    bias_d = aux_d = None
+    if bias is not None:
+        flags |= _lib.GEMM_BIAS
+        bias_d = dev(bias, torch.float32)
+    if relu:
+        flags |= _lib.GEMM_RELU
+    if aux is not None:
+        flags |= _lib.GEMM_RELU_MASK
+        aux_d = dev(aux, torch.bfloat16)
+    if out_bf16:
+        flags |= _lib.GEMM_OUT_BF16
+    need = int(lib.afr_op_gemm_fix_workspace_bytes(M, N, head_tiles, splitk))
+    ws = torch.zeros(need, dtype=torch.uint8, device="cuda")
+    outs = []
+    for _ in range(repeats):
+        Cd = torch.full((M, N), float("nan"), dtype=torch.bfloat16 if out_bf16 else torch.float32, device="cuda")
+        _lib.check(lib.afr_op_gemm_fix(flags, ptr(A), ptr(B), ptr(Cd), ptr(bias_d), ptr(aux_d), M, N, K, M if a_kstrided else K,
+                                       N if b_kstrided else K, N, N, head_tiles, splitk, ptr(ws), need, stream()))
+        torch.cuda.synchronize()
+        outs.append(Cd.float().cpu())
+    tiles = ((M + 255) // 256) * ((N + 255) // 256)
+    tail = tiles - min(head_tiles, tiles)
+    counters = ws[tail * splitk * 256 * 256 * 4:].view(torch.int32).cpu()
+    return outs, counters

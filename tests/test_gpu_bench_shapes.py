@@ -174,6 +174,32 @@ def test_wide_bf16_gemm_epilogues_and_splitk():
         assert float((got.double() - ref2).abs().max()) < 2e-5 * float(ref2.abs().max()), sk
 
 
+@pytest.mark.parametrize("M,N,K,head,sk,ak,bk", [
+    (1024, 19200, 6400, 256, 5, False, False),     # R0 fc_output forward: one full round whole + 44 tail tiles cut 5 ways
+    (1024, 6400, 19200, 0, 2, False, True),        # R0 fc_output input gradient: 100 tiles cut 2 ways
+    (520, 776, 2120, 1, 3, False, False),          # ragged tiles, K not a multiple of the slice length, one head tile
+    (520, 776, 2120, 0, 4, True, True),            # both operands k-strided
+    (304, 520, 4096, 6, 2, True, False),           # head_tiles == tiles: nothing is split
+])
+def test_in_launch_splitk_gemm(M, N, K, head, sk, ak, bk):
+    """afr_op_gemm_fix (the form afr_train_step uses for the sheet model's fc_output products): every epilogue against
+    fp64, the arrival counters left at zero, and bitwise equal results from launch to launch (the slices are added in
+    slice order whichever workgroup arrives last)."""
+    from .gpu_util import gemm_fix
+    A, B = _b16(_rand(151, (M, K))), _b16(_rand(152, (N, K), 0.2))
+    bias, aux = _rand(153, (N,)), _b16(_rand(154, (M, N)))
+    ref = A.double() @ B.double().t()
+    scale = float(ref.abs().max())
+    outs, cnt = gemm_fix(A, B, head, sk, a_kstrided=ak, b_kstrided=bk, repeats=3)
+    assert float((outs[0].double() - ref).abs().max()) < 2e-5 * scale
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    assert int(cnt.abs().max()) == 0
+    outs, _ = gemm_fix(A, B, head, sk, a_kstrided=ak, b_kstrided=bk, bias=bias, relu=True, out_bf16=True)
+    assert float((outs[0].double() - torch.relu(ref + bias.double())).abs().max()) < 1e-2 * scale
+    outs, _ = gemm_fix(A, B, head, sk, a_kstrided=ak, b_kstrided=bk, aux=aux, out_bf16=True)
+    assert float((outs[0].double() - ref * (aux > 0)).abs().max()) < 1e-2 * scale
+
+
 # ----------------------------------------------------------------------------- bit-exact gather (north star)
 @pytest.mark.parametrize("cfgkw,B,xmax", [
     (dict(hidden=(1024, 1024), out_h=32, out_w=32, n_fonts=2), 8192, None),       # C3: folded first layer (table gather)

@@ -144,6 +144,30 @@ def test_reference_batch_r0_full_size_bf16_with_dropout_tracks_the_f32_engine():
         assert rel < 5e-2, (k, rel)
 
 
+def test_r0_input_gradient_as_in_launch_splitk_matches_the_default_kernels():
+    """config.reserved bit 3: fc_output's input-gradient product on 256x256 tiles with the split-K sum inside the launch.
+    Same bf16 operands and f32 accumulation, another summation order: gradients equal the default path's to f32 rounding
+    (the front end's gradients come through a bf16 dz, so to a bf16 ulp there), and the step stays bitwise reproducible."""
+    B = 512
+    x = torch.from_numpy(synth.encode_strings(synth.dataset_strings(B), 100)).cuda()
+    t = torch.from_numpy(synth.synth_sheet_targets(B, 80, 240, tensor_id=975)).cuda()
+    res = {}
+    for flags in (0, 8):
+        eng = _engine(R0, dtype="bf16", max_batch=B, with_optimizer=False, flags=flags)
+        eng.train_step(x, t, step=3, do_step=False)
+        g, l = eng.flat_grads.clone(), eng.read_loss()
+        eng.train_step(x, t, step=3, do_step=False)
+        assert torch.equal(eng.flat_grads, g) and eng.read_loss() == l, flags
+        res[flags] = (l, {k: v.clone() for k, v in eng.grads.items()})
+        del eng
+        torch.cuda.empty_cache()
+    assert res[0][0] == res[8][0]                         # the forward is the same launch
+    for k, ref in res[0][1].items():
+        rel = float((res[8][1][k] - ref).norm() / ref.norm().clamp_min(1e-12))
+        assert rel < 4e-3, (k, rel)
+    assert torch.equal(res[0][1]["fc_output.weight"], res[8][1]["fc_output.weight"])     # not downstream of dz
+
+
 def test_fused_optimizer_step_equals_unfused_step():
     """afr_train_step fuses AdamW of fc_output.weight into its dW GEMM; the result must equal backward + afr_adamw_step."""
     from .util import SheetConfig
