@@ -247,7 +247,7 @@ def main():
         # optimizer (26 B of p/m/v traffic per output element; 8(d): "bf16 mode: HBM until B >~ 2700/GPU").
         secs = dom["avg_ms"] * 1e-3
         kern = dom["kernel"]
-        f32_kernel = kern.startswith(("sheet_", "gemm_f32"))
+        f32_kernel = kern.startswith(("sheet_", "gemm_f32")) or "<f32>" in kern
         peak_fl = PEAK["f32"] if f32_kernel else PEAK[dtype]           # f32 VALU peak == f32 MFMA peak (157.3 TF)
         fl = dom["algo_flops"] / secs / 1e12
         by = dom["algo_bytes"] / secs / 1e9
@@ -255,8 +255,8 @@ def main():
         if hbm_bound:
             roof = {"bound": "hbm", "kernel": kern, "achieved": by, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": by / HBM_PEAK_GBS}
         else:
-            roof = {"bound": "mfma" if kern.startswith("gemm") else "valu", "kernel": kern, "achieved": fl, "peak": peak_fl,
-                    "unit": "TFLOP/s", "frac": fl / peak_fl}
+            # every dense product of the path runs on the matrix cores (the f32 forms at the f32 VALU's rate, 157.3 TF)
+            roof = {"bound": "mfma", "kernel": kern, "achieved": fl, "peak": peak_fl, "unit": "TFLOP/s", "frac": fl / peak_fl}
         tr, src = pmc_traffic(name, kern) if (dtype == DEFAULT_DTYPE[name] and not args.batch) else (None, None)
         roof.update({"traffic": tr, "traffic_unit": f"bytes/launch (PMC FETCH_SIZE x2 + WRITE_SIZE, {src})" if src else None,
                      "avg_launch_ms": dom["avg_ms"], "launches": dom["launches"], "algo_flops_per_launch": dom["algo_flops"],
@@ -275,6 +275,13 @@ def main():
                 if r["kernel"].startswith("gemm") and ori in r["kernel"] and r["kernel"].endswith(sh) and role not in wl and r["avg_ms"] > 0:
                     tf = r["algo_flops"] / (r["avg_ms"] * 1e-3) / 1e12
                     wl[role] = {"kernel": r["kernel"], "avg_us": r["avg_ms"] * 1e3, "tflops": tf, "frac": tf / (PEAK["f32"] if "f32" in r["kernel"] else PEAK[dtype])}
+        # a layer's weight and input gradients leave as ONE grouped launch when both qualify (afr_gemm_pair_plan)
+        for r in table:
+            if r["kernel"].startswith("gemm_bf16_group") and shapes["dX"][1][1:-1] in r["kernel"] and shapes["dW"][1][1:-1] in r["kernel"] \
+                    and "dW+dX" not in wl and r["avg_ms"] > 0:
+                tf = r["algo_flops"] / (r["avg_ms"] * 1e-3) / 1e12
+                wl["dW+dX"] = {"kernel": r["kernel"], "avg_us": r["avg_ms"] * 1e3, "tflops": tf, "frac": tf / PEAK[dtype],
+                               "note": "weight gradient (split-K slabs) and input gradient of the layer in one grouped launch"}
         roof["widest_linear"] = {"layer": f"{wk}->{wn}", "source": "hipEvent brackets, warm-up steps (every launch timed)", **wl}
         out = {
             "metric": "glyphs/sec training (batch fwd+bwd+step)", "value": value, "unit": "glyphs/s", "n_gpus": world,
