@@ -98,7 +98,8 @@ struct afr_plan {
     bool have_du = false;
     int next_stage = 0;
     // profiling
-    int prof_mode = 0;      // 0 off, 1 every launch, 2 only prof_only
+    int prof_mode = 0;      // 0 off, 1 every launch, 2 only prof_only, 3 every 4th launch of prof_only
+    unsigned prof_seen = 0; // launches of prof_only met in mode 3
     std::string prof_only_sym;   // mode 2: the kernel symbol to keep timing
     double prof_overhead_ms = -1.0;   // event-bracket overhead, measured on first use (prof_calibrate)
     std::vector<ProfRec> prof;
@@ -371,7 +372,8 @@ struct ProfScope {
         if (!on) return;
         if (p->prof_overhead_ms < 0.0) prof_calibrate(p, s);
         r.tag = tag_id(p, tag);
-        if (p->prof_mode == 2 && symbol_of(p->prof_tags[r.tag]) != p->prof_only_sym) { on = false; return; }
+        if (p->prof_mode >= 2 && symbol_of(p->prof_tags[r.tag]) != p->prof_only_sym) { on = false; return; }
+        if (p->prof_mode == 3 && (p->prof_seen++ & 3u)) { on = false; return; }     // a sample: every 4th launch
         r.flops = flops; r.bytes = bytes; r.a = ev_get(p); r.b = ev_get(p);
         (void)hipEventRecord(r.a, s);
     }
@@ -407,7 +409,7 @@ static std::vector<SymAgg> prof_by_symbol(afr_plan* p, const std::vector<double>
 }
 extern "C" int afr_profile_dominant(afr_plan* p, int mode) {
     if (!p) return fail(AFR_EINVAL, "null plan");
-    if (mode == 2) {     // keep timing only the kernel (symbol) that dominated the launches recorded so far
+    if (mode == 2 || mode == 3) {     // keep timing only the kernel (symbol) that dominated the launches recorded so far
         if (p->prof.empty() && p->prof_only_sym.empty())
             return fail(AFR_ESTATE, "mode 2 needs a mode-1 recording to pick the dominant kernel from");
         if (!p->prof.empty() && p->prof_mode == 1) {
@@ -423,6 +425,7 @@ extern "C" int afr_profile_dominant(afr_plan* p, int mode) {
     for (auto& r : p->prof) { p->ev_pool.push_back(r.a); p->ev_pool.push_back(r.b); }
     p->prof.clear();
     p->prof_mode = mode;
+    p->prof_seen = 0;
     return AFR_OK;
 }
 extern "C" int afr_profile_read(afr_plan* p, char* name, int cap, double* avg_ms, int64_t* launches, double* flops,

@@ -171,14 +171,18 @@ def measure(name, dtype, B, K, W, rank, world, dist, with_roofline=True):
 
     table, dom = [], None
     if with_roofline:
-        # warm-up; its last steps run with every launch timed, to find the dominant kernel and the per-shape table
-        run(max(W - 3, 1))
-        torch.cuda.synchronize()
+        # W warm-up steps.  The first of them (up to 3) run with every launch bracketed by events, to find the dominant kernel
+        # and the per-shape table; reading that table back leaves the GPU idle for milliseconds, so it comes BEFORE the rest
+        # of the warm-up: the timed region then starts on a GPU that has just been running the step, not on an idle one.
+        n0 = 1 if W >= 2 else 0                                       # the very first step pays one-time costs (code-object load)
+        run(n0)
+        n1 = min(max(W - n0, 1), 3)
         eng.profile(1)
-        run(min(W, 3) if W > 0 else 1)
+        run(n1)
         torch.cuda.synchronize()
         table = eng.profile_table()
-        eng.profile(2)                                                # timed region: events around the dominant kernel only
+        eng.profile(3)                                                # from here on: events around every 4th launch of the dominant kernel
+        run(max(W - n0 - n1, 0))
     else:
         run(max(W, 1))
     fence()

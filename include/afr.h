@@ -147,7 +147,8 @@ int afr_error_flags(afr_plan* plan, void* stream, uint32_t* flags_out);
 /* Name and average duration (ms, hipEvent-timed on the launch stream) of the plan's dominant
  * kernel over the calls since the last reset; bench.py's roofline leg.  mode 0: off; 1: time every
  * launch (to find the dominant kernel); 2: from now on time only the kernel that dominated the
- * mode-1 recording (two events per launch of that kernel: cheap enough for a timed region). */
+ * mode-1 recording (two events per launch of that kernel); 3: like 2 but only every 4th launch of it -- an event
+ * record also holds back the next kernel's start (~3.5 us each on MI355X), a sample keeps a timed region honest. */
 int afr_profile_dominant(afr_plan* plan, int mode);
 int afr_profile_read(afr_plan* plan, char* name, int name_cap, double* avg_ms, int64_t* launches,
                      double* algo_flops, double* algo_bytes);
