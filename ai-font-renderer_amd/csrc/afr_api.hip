@@ -83,6 +83,7 @@ struct afr_plan {
     bool fused1 = false;
     bool wT_valid = false;         // bf16: the transposed operand copies W1T / W2T match the current parameters
     size_t o_w1t = 0, o_w2t = 0, o_slab1 = 0;
+    bool l1f = false; size_t o_l1f = 0;   // glyph, bf16: folded first layer's backward in one kernel (slabs [blocks][dW1|db1|dTab])
     size_t o_fix = 0, o_fixcnt = 0; bool have_fix = false;   // in-launch split-K: slice parking area + per-tile arrival counters
     // glyph layer table
     struct Layer { int N, K; int64_t w_off, b_off; int sk = 1; size_t o_slab_w = 0, o_slab_b = 0; };
@@ -127,7 +128,7 @@ static int64_t off_of(const afr_plan* p, const char* name) {
     return -1;
 }
 
-static_assert(AFR_RT_MAXSEG >= 2 * (AFR_MAX_HIDDEN + 1) + 4, "a backward pass of the deepest glyph net must fit one grouped reduce");
+static_assert(AFR_RT_MAXSEG >= 2 * AFR_MAX_HIDDEN + 2 * AFR_L1F_MAX_SPLIT + 4, "a backward pass of the deepest glyph net must fit one grouped reduce");
 #ifndef AFR_SPLITK_TARGET
 #define AFR_SPLITK_TARGET 512
 #endif
@@ -254,6 +255,12 @@ extern "C" int afr_plan_create(const afr_config* c, afr_plan** out) {
             if (lb > eb) eb = lb;
             p->o_table = carve((size_t)(c->vocab + c->n_fonts) * c->hidden[0] * sizeof(float));
             p->o_dw1 = carve((size_t)c->hidden[0] * E * sizeof(float));
+            if (afr_glyph_l1_bwd_fused_eligible(c->dtype, E, c->hidden[0], c->vocab, c->n_fonts)) {
+                p->l1f = true;
+                // worst case over batch sizes <= max_batch: every 64-glyph block with the full-width slab, or 256 blocks of the narrowest
+                p->o_l1f = carve(((size_t)((B + 63) / 64) + 256) * (size_t)((size_t)c->hidden[0] * E + c->hidden[0] + (size_t)(c->vocab + c->n_fonts) * E) * sizeof(float));
+                p->o_w1t = carve((size_t)c->hidden[0] * E * 2);
+            }
         }
         p->o_slab_e = carve(eb * (size_t)(c->vocab + c->n_fonts) * E * sizeof(float));
         if (c->n_hidden == 1 && afr_glyph1_eligible(E, c->hidden[0], Pix, c->vocab, c->n_fonts) &&
@@ -263,7 +270,7 @@ extern "C" int afr_plan_create(const afr_config* c, afr_plan** out) {
             p->o_slab1 = carve(nblk * (size_t)p->total * sizeof(float));
             p->o_loss = carve((1040 + nblk + 64) * sizeof(float));           // room for one loss partial per block
             if (c->dtype == AFR_BF16) {
-                p->o_w1t = carve((size_t)c->hidden[0] * E * 2);
+                if (!p->l1f) p->o_w1t = carve((size_t)c->hidden[0] * E * 2);
                 p->o_w2t = carve((size_t)Pix * c->hidden[0] * 2);
             }
         }
@@ -633,7 +640,8 @@ static int forward_impl(afr_plan* p, const int64_t* x, const int64_t* font, int 
             const auto& l = p->layers[0];
             ProfScope ps(p, s, "glyph_l1_fwd", 0.0, (double)B * l.N * p->act_bytes);
             HIPCHK(afr_launch_glyph_l1_fwd(c.dtype, p->P + p->emb_off, femb, p->P + l.w_off, p->P + l.b_off, x, font, B, c.embed_dim,
-                                           l.N, c.vocab, c.n_fonts, (float*)(p->ws + p->o_table), h, p->ws + p->o_act[1], err, s));
+                                           l.N, c.vocab, c.n_fonts, (float*)(p->ws + p->o_table), h, p->ws + p->o_act[1], err, s,
+                                           p->l1f ? (void*)(p->ws + p->o_w1t) : nullptr));
             h = p->ws + p->o_act[1];
             first = 1;
         } else {
@@ -752,6 +760,27 @@ static int backward_stage_impl(afr_plan* p, int stage, int64_t* g_off, int64_t* 
         // and the per-table-row segment sums; a small kernel turns those into dEmb / dFont.  No input-gradient GEMM,
         // no scatter-add.
         const int K0 = p->k0, E = c.embed_dim;
+        if (p->l1f && !(c.reserved & 16)) {
+            // throughput mode: one kernel per 64 glyphs (gemm.hip: glyph_l1_bwd_fused_kernel) -> [dW1 | db1 | dTab] slabs
+            float* sl = (float*)(p->ws + p->o_l1f);
+            const int CS = afr_glyph_l1_bwd_fused_split(B, l.N), nb = afr_glyph_l1_bwd_fused_blocks(B, l.N), nc = l.N / CS;
+            const long long st = afr_glyph_l1_bwd_fused_slab_floats(B, l.N, c.vocab, c.n_fonts);
+            {
+                ProfScope ps(p, s, "glyph_l1_bwd_fused", 2.0 * B * l.N * (2.0 * E + 1.0), (double)B * l.N * 2.0 + (double)nb * st * 4.0);
+                HIPCHK(afr_launch_glyph_l1_bwd_fused(dy, l.N, a, K0, p->ws + p->o_w1t, p->last_x, p->last_font, B, l.N, c.vocab, c.n_fonts, sl, s));
+            }
+            // block = (row block, column range): range cs's slabs are blocks cs, cs + CS, ...; every block has a dTab partial
+            for (int cs = 0; cs < CS; ++cs) {
+                afr_rtable_add(rt, p->G + l.w_off + (size_t)cs * nc * E, sl + (size_t)cs * st, nb / CS, st * CS, (long long)nc * E);
+                afr_rtable_add(rt, p->G + l.b_off + (size_t)cs * nc, sl + (size_t)cs * st + (size_t)nc * E, nb / CS, st * CS, nc);
+            }
+            afr_rtable_add(rt, p->G + p->emb_off, sl + (size_t)nc * E + nc, nb, st, (long long)c.vocab * E);
+            if (c.n_fonts > 0) afr_rtable_add(rt, p->G + p->font_off, sl + (size_t)nc * E + nc + (size_t)c.vocab * E, nb, st, (long long)c.n_fonts * E);
+            if ((rc = flush())) return rc;
+            if (g_off) *g_off = 0;
+            if (g_len) *g_len = l.b_off + (l.N + 63) / 64 * 64;
+            return AFR_OK;
+        }
         int sk = choose_splitk(l.N, K0, B);
         if (sk > l.sk) sk = l.sk;
         float* sw = (float*)(p->ws + l.o_slab_w);
@@ -889,12 +918,14 @@ static int reduce_and_step(afr_plan* p, hipStream_t s, RTable& rt, float lr, flo
     if (rc) return rc;
     for (const Tensor& tn : p->params) {
         if (tn.off == skip_off) continue;
-        bool covered = false;
-        for (int i = 0; i < rt.nseg && !covered; ++i) {
-            const int64_t so = rt.seg[i].dst - p->G, sl = rt.seg[i].n4 * 4;
-            covered = tn.off >= so && tn.off + tn.numel <= so + sl;
+        // covered by the (disjoint) segments of the grouped reduce -- possibly several per tensor (column ranges)?
+        int64_t cov = 0;
+        for (int i = 0; i < rt.nseg; ++i) {
+            const int64_t so = rt.seg[i].dst - p->G, se = so + rt.seg[i].n4 * 4;
+            const int64_t lo = so > tn.off ? so : tn.off, hi = se < tn.off + tn.numel ? se : tn.off + tn.numel;
+            if (hi > lo) cov += hi - lo;
         }
-        if (covered) continue;
+        if (cov >= tn.numel) continue;
         const int64_t n = (tn.numel + 63) / 64 * 64;
         ProfScope ps(p, s, "adamw", 0.0, (double)n * 28.0);
         HIPCHK(afr_launch_adamw(p->P + tn.off, p->G + tn.off, p->M + tn.off, p->V + tn.off, shadow ? shadow + tn.off : nullptr, n, lr, b1,

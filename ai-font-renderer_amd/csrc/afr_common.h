@@ -150,7 +150,8 @@ struct RSeg {
 };
 // every gradient tensor of the deepest glyph net (AFR_MAX_HIDDEN + 1 Linears: weight + bias each) plus the folded first
 // layer's extra segments (compact dW1, embedding and font partials) fits; afr_api.hip static_asserts it
-constexpr int AFR_RT_MAXSEG = 24;
+constexpr int AFR_RT_MAXSEG = 32;
+constexpr int AFR_L1F_MAX_SPLIT = 4;   // column ranges per row block of the fused first-layer backward (2 segments each)
 struct RTable {
     int nseg = 0; int nblocks = 0; int overflow = 0;
     // optional fused optimizer: the summed gradient is not stored; AdamW is applied to p/m/v at the same flat offset
@@ -181,9 +182,16 @@ hipError_t afr_launch_glyph_embed(int act_dtype, const float* emb, const float* 
 int afr_embed_bwd_blocks(int B);
 hipError_t afr_launch_glyph_l1_fwd(int act_dtype, const float* emb, const float* font_emb, const float* W1, const float* b1,
                                    const int64_t* x, const int64_t* font, int B, int E, int N1, int vocab, int n_fonts,
-                                   float* table, void* h0, void* h1, uint32_t* err_flag, hipStream_t s);
+                                   float* table, void* h0, void* h1, uint32_t* err_flag, hipStream_t s, void* w1t = nullptr);
 int afr_glyph_k0(int E, int vocab, int n_fonts);
 int afr_glyph_l1_bwd_blocks(int N1);
+// the same backward in one kernel (throughput mode, gemm.hip: glyph_l1_bwd_fused_kernel); W1T = bf16 [E][N1] from the forward
+bool afr_glyph_l1_bwd_fused_eligible(int dtype, int E, int N1, int vocab, int n_fonts);
+int afr_glyph_l1_bwd_fused_split(int B, int N1);                                  // column ranges per block of 64 glyphs
+int afr_glyph_l1_bwd_fused_blocks(int B, int N1);
+long long afr_glyph_l1_bwd_fused_slab_floats(int B, int N1, int vocab, int n_fonts);   // [dW1 nc*E | db1 nc | dTab rows*E], nc = N1 / split
+hipError_t afr_launch_glyph_l1_bwd_fused(const void* d1, int ldd, const void* h0, int ldh, const void* W1T, const int64_t* x,
+                                         const int64_t* font, int B, int N1, int vocab, int n_fonts, float* slabs, hipStream_t s);
 hipError_t afr_launch_glyph_l1_bwd(const float* slabs, int nslabs, long long slab_stride, const float* W1, int N1, int E,
                                    int vocab, int n_fonts, float* dw1, float* dtab_part, hipStream_t s);
 hipError_t afr_launch_glyph_embed_bwd(int act_dtype, const void* d, const int64_t* x, const int64_t* font, int B,

@@ -371,7 +371,7 @@ hipError_t afr_launch_glyph_embed(int act_dtype, const float* emb, const float* 
 constexpr int GT_ROWS = 8;
 __global__ __launch_bounds__(256) void glyph_table_kernel(const float* __restrict__ emb, const float* __restrict__ femb,
                                                           const float* __restrict__ W1, int vocab, int rows, int E, int N1,
-                                                          float* __restrict__ table) {
+                                                          float* __restrict__ table, bf16_t* __restrict__ w1t) {
     extern __shared__ float sm[];                         // W [256][E+1] | tab [GT_ROWS][E]
     float* Ws = sm;
     float* tab = sm + 256 * (E + 1);
@@ -390,6 +390,9 @@ __global__ __launch_bounds__(256) void glyph_table_kernel(const float* __restric
     __syncthreads();
     if ((int)threadIdx.x >= nn) return;
     const float* w = Ws + threadIdx.x * (E + 1);
+    // the first row of blocks also leaves W1^T as bf16 [E][N1] (the fused first-layer backward reads fc1's weights k-contiguous)
+    if (w1t && blockIdx.x == 0)
+        for (int k = 0; k < E; ++k) w1t[(size_t)k * N1 + n0 + threadIdx.x] = (bf16_t)w[k];
     float a[GT_ROWS];
 #pragma unroll
     for (int j = 0; j < GT_ROWS; ++j) a[j] = 0.f;
@@ -472,7 +475,7 @@ __global__ __launch_bounds__(256) void glyph_l1_fwd_kernel(const float* __restri
 }
 hipError_t afr_launch_glyph_l1_fwd(int act_dtype, const float* emb, const float* font_emb, const float* W1, const float* b1,
                                    const int64_t* x, const int64_t* font, int B, int E, int N1, int vocab, int n_fonts,
-                                   float* table, void* h0, void* h1, uint32_t* err_flag, hipStream_t s) {
+                                   float* table, void* h0, void* h1, uint32_t* err_flag, hipStream_t s, void* w1t) {
     if (B <= 0) return hipSuccess;
     if ((N1 & 7) || (E & 7)) return hipErrorInvalidValue;
     const int K0 = afr_glyph_k0(E, vocab, n_fonts);
@@ -486,7 +489,7 @@ hipError_t afr_launch_glyph_l1_fwd(int act_dtype, const float* emb, const float*
         if (dev >= 0 && dev < 16) tlds_set[dev] = tlds;
     }
     hipLaunchKernelGGL(glyph_table_kernel, dim3((rows + GT_ROWS - 1) / GT_ROWS, (N1 + 255) / 256), dim3(256), tlds, s, emb, font_emb,
-                       W1, vocab, rows, E, N1, table);
+                       W1, vocab, rows, E, N1, table, (bf16_t*)w1t);
     dim3 g(grid_for((long long)B * ((N1 + K0) / 8), 256, 8192)), b(256);
     if (act_dtype == AFR_BF16)
         hipLaunchKernelGGL(glyph_l1_fwd_kernel<bf16_t>, g, b, 0, s, table, b1, emb, font_emb, x, font, B, E, N1, vocab, n_fonts, K0,

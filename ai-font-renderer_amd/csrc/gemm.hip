@@ -1122,6 +1122,129 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_lab256(GemmGroup g) {
     gemm_bf16_256_body<0, 0, ABL>(g.p[0], blockIdx.x, gridDim.x, smem);
 }
 #endif
+
+// ------------------------------------------------------------ folded first layer of the glyph nets: backward in ONE kernel
+// (throughput mode).  Inputs: d1 = d(loss)/d(pre-activation of fc1) [B][N1] (the layer above already applied the ReLU mask),
+// h0 = Emb[x] + Font[f] [B][E] (the first E columns of the forward's h0'), the codes, and W1^T (bf16 [E][N1], left behind by
+// the forward's table kernel).  A workgroup owns 64 glyphs, stages their d1 rows ONCE (128 KiB: the [k = glyph][x = n] images
+// of the GEMM's k-strided operand, so both the row-contiguous and the hardware-transposed reads below hit the same bytes)
+// and computes, all on the matrix cores:
+//     dh0[b][e]  = sum_n d1[b][n] W1[n][e]                       (A rows b from LDS, B rows e of W1^T from L2)
+//     dW1[n][e]  = sum_b d1[b][n] h0[b][e],  db1[n] = sum_b d1[b][n]      (h0 image carries a column of ones at x = E)
+//     dTab[v][e] = sum_b onehot[b][v] dh0[b][e]                   (nn.Embedding's scatter-add as a product; model.py:309)
+// and leaves them in its slab [dW1 | db1 | dTab]; the grouped reduce adds the slabs in block order.  This replaces a
+// weight-gradient GEMM against the 168-column widened operand (2.8 GFLOP, 14.5 us of mostly fixed cost, 22 MB of split-K
+// slabs) and the kernel that post-processed its slabs (9 us).
+struct L1BwdArgs {
+    const bf16_t* d1; const bf16_t* h0; const bf16_t* W1T; const int64_t* x; const int64_t* font;
+    int ldd, ldh, B, N1, vocab, n_fonts;
+    int CS, ncols;                   // the N1 columns are cut into CS ranges of ncols (a multiple of 128): block = (row block, range)
+    float* slabs; long long slab_stride; int o_b, o_tab;
+};
+constexpr int L1_E = 32, L1_R = 64, L1_LDR = L1_R + 8;       // embedding width (compile time), glyphs per block, padded row of the overlay
+__global__ __launch_bounds__(512) void glyph_l1_bwd_fused_kernel(L1BwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char sm[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 15, q = lane >> 4;
+    const int NS = a.ncols >> 7;                             // 128-column sub-tiles of this block's d1 columns
+    const int rb = blockIdx.x / a.CS, n_lo = (blockIdx.x - rb * a.CS) * a.ncols;
+    const int b0 = rb * L1_R, nb = min(L1_R, a.B - b0);
+    char* Dimg = sm;                                         // [NS] images [64 k][128 x], 16 KiB each
+    char* Himg = sm + NS * SUB;                              // h0 image (x < E valid, x == E: ones)
+    int* ids = reinterpret_cast<int*>(sm + (NS + 1) * SUB);  // [64] codes, [64] vocab + font id (or -1)
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)sm;
+    float* slab = a.slabs + (size_t)blockIdx.x * a.slab_stride;
+    {
+        const i32x4 rD = make_rsrc(a.d1), rH = make_rsrc(a.h0);
+        const int pieces = (NS + 1) * 16;
+        for (int pc = wave; pc < pieces; pc += 8) {
+            const int sidx = pc >> 4, inst = pc & 15;
+            if (sidx < NS) stage_inst<1>(rD, lds0 + sidx * SUB, a.ldd, a.N1, n_lo + sidx * 128, b0, b0 + nb, inst, lane);
+            else stage_inst<1>(rH, lds0 + NS * SUB, a.ldh, L1_E, 0, b0, b0 + nb, inst, lane);
+        }
+        if (tid < L1_R) {
+            long long xi = tid < nb ? a.x[b0 + tid] : 0, fi = (tid < nb && a.n_fonts > 0 && a.font) ? a.font[b0 + tid] : 0;
+            xi = min(max(xi, 0ll), (long long)a.vocab - 1);                  // out-of-range codes were flagged by the forward
+            if (a.n_fonts > 0) fi = min(max(fi, 0ll), (long long)a.n_fonts - 1);
+            ids[tid] = (int)xi; ids[L1_R + tid] = a.n_fonts > 0 ? a.vocab + (int)fi : -1;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid < nb) {                                      // the ones column: element (k = tid, x = E) of the h0 image
+            const int k = tid, xx = L1_E;
+            *reinterpret_cast<unsigned short*>(Himg + k * 256 + (((xx >> 4) ^ fswz(k)) << 5) + (xx & 15) * 2) = 0x3F80;   // bf16 1.0
+        }
+        __syncthreads();
+    }
+    // ---- dh0 tile of this wave: glyph rows (wave>>1)*16.., embedding columns (wave&1)*16..; reduction over all N1
+    f32x4 dh0 = {0.f, 0.f, 0.f, 0.f};
+    {
+        const int brow = (wave >> 1) * 16 + r, erow = (wave & 1) * 16 + r;
+        const bf16_t* wrow = a.W1T + (size_t)erow * a.N1 + n_lo + 8 * q;
+        const int nks = a.ncols >> 5;
+        for (int k0 = 0; k0 < nks; k0 += 4) {                // ncols is a multiple of 128: whole groups of 4 k-steps
+            bf16x8 wv[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) wv[j] = *reinterpret_cast<const bf16x8*>(wrow + (k0 + j) * 32);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int n = (k0 + j) * 32 + 8 * q, xx = n & 127;
+                const bf16x8 av = *reinterpret_cast<const bf16x8*>(Dimg + (n >> 7) * SUB + brow * 256 + (((xx >> 4) ^ fswz(brow)) << 5) + (xx & 15) * 2);
+                dh0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, wv[j], dh0, 0, 0, 0);
+            }
+        }
+    }
+    // ---- dW1 / db1: output tiles [16 n][48 e'] (e' = 32: the ones column), reduction over the block's 64 glyphs
+    {
+        bf16x8 hf[3][2];
+#pragma unroll
+        for (int et = 0; et < 3; ++et)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) hf[et][ks] = read_frag<1>(Himg, et * 16, ks, lane);
+        for (int nt = wave; nt < (a.ncols >> 4); nt += 8) {
+            const char* S = Dimg + (nt >> 3) * SUB;
+            const bf16x8 d0 = read_frag<1>(S, (nt & 7) * 16, 0, lane), d1v = read_frag<1>(S, (nt & 7) * 16, 1, lane);
+            f32x4 acc[3];
+#pragma unroll
+            for (int et = 0; et < 3; ++et) {
+                acc[et] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                acc[et] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hf[et][0], d0, acc[et], 0, 0, 0);    // D[e' = 4q + i][n = r]
+                acc[et] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hf[et][1], d1v, acc[et], 0, 0, 0);
+            }
+            const int n = nt * 16 + r;                       // within this block's column range
+            *reinterpret_cast<f32x4*>(slab + (size_t)n * L1_E + 4 * q) = acc[0];
+            *reinterpret_cast<f32x4*>(slab + (size_t)n * L1_E + 16 + 4 * q) = acc[1];
+            if (q == 0) slab[a.o_b + n] = acc[2][0];
+        }
+    }
+    __syncthreads();                                         // every read of the d1 / h0 images is done: the area is reused
+    // ---- embedding_dense_backward as one more product (as glyph1_step_kernel): dh0^T [E][64] and the one-hot image [VT][64]
+    bf16_t* dh0T = reinterpret_cast<bf16_t*>(sm);
+    bf16_t* ohT = dh0T + L1_E * L1_LDR;
+    const int rows_tot = a.vocab + a.n_fonts, VT = (rows_tot + 15) & ~15;
+    for (int i = tid; i < VT * L1_LDR * 2 / 16; i += 512) reinterpret_cast<i32x4*>(ohT)[i] = (i32x4){0, 0, 0, 0};
+    {
+        bf16_t* d = dh0T + ((wave & 1) * 16 + r) * L1_LDR + (wave >> 1) * 16 + 4 * q;       // D[b = 4q + i][e = r]: 4 consecutive b
+        *reinterpret_cast<bf16x4*>(d) = (bf16x4){(bf16_t)dh0[0], (bf16_t)dh0[1], (bf16_t)dh0[2], (bf16_t)dh0[3]};
+    }
+    __syncthreads();
+    if (tid < nb) {
+        ohT[ids[tid] * L1_LDR + tid] = (bf16_t)1.f;
+        if (ids[L1_R + tid] >= 0) ohT[ids[L1_R + tid] * L1_LDR + tid] = (bf16_t)1.f;
+    }
+    __syncthreads();
+    for (int t = wave; t < (VT >> 4) * 2; t += 8) {
+        const int vt = t >> 1, et = t & 1;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const bf16x8 av = *reinterpret_cast<const bf16x8*>(dh0T + (et * 16 + r) * L1_LDR + ks * 32 + 8 * q);
+            const bf16x8 bv = *reinterpret_cast<const bf16x8*>(ohT + (vt * 16 + r) * L1_LDR + ks * 32 + 8 * q);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv, acc, 0, 0, 0);            // D[e = 4q + i][v = r]
+        }
+        const int v = vt * 16 + r;
+        if (v < rows_tot) *reinterpret_cast<f32x4*>(slab + a.o_tab + (size_t)v * L1_E + et * 16 + 4 * q) = acc;
+    }
+}
 }  // namespace bf16k
 
 // ---------------------------------------------------------------------------------------- launch
@@ -1297,5 +1420,42 @@ hipError_t afr_launch_gemm(int dtype, const GemmParams& p, hipStream_t s) {
         else LF(1, 1);
 #undef LF
     }
+    return hipGetLastError();
+}
+
+// ---- folded first layer, fused backward (bf16)
+bool afr_glyph_l1_bwd_fused_eligible(int dtype, int E, int N1, int vocab, int n_fonts) {
+    return dtype == AFR_BF16 && E == bf16k::L1_E && N1 % 128 == 0 && N1 >= 256 && N1 <= 1024 && vocab + n_fonts <= 144 && !getenv("AFR_NO_L1_FUSED");
+}
+// column ranges per row block: enough blocks to cover the chip, ranges of whole 128-column sub-tiles
+int afr_glyph_l1_bwd_fused_split(int B, int N1) {
+    const int nrb = (B + bf16k::L1_R - 1) / bf16k::L1_R;
+    int cs = 1;
+    while (cs * 2 <= AFR_L1F_MAX_SPLIT && cs * 2 * nrb <= 256 && N1 % (cs * 2 * 128) == 0) cs *= 2;
+    return cs;
+}
+int afr_glyph_l1_bwd_fused_blocks(int B, int N1) { return (B + bf16k::L1_R - 1) / bf16k::L1_R * afr_glyph_l1_bwd_fused_split(B, N1); }
+long long afr_glyph_l1_bwd_fused_slab_floats(int B, int N1, int vocab, int n_fonts) {
+    const int nc = N1 / afr_glyph_l1_bwd_fused_split(B, N1);
+    return (long long)nc * bf16k::L1_E + nc + (long long)(vocab + n_fonts) * bf16k::L1_E;
+}
+hipError_t afr_launch_glyph_l1_bwd_fused(const void* d1, int ldd, const void* h0, int ldh, const void* W1T, const int64_t* x,
+                                         const int64_t* font, int B, int N1, int vocab, int n_fonts, float* slabs, hipStream_t s) {
+    if (B <= 0) return hipSuccess;
+    bf16k::L1BwdArgs a;
+    a.d1 = (const bf16_t*)d1; a.h0 = (const bf16_t*)h0; a.W1T = (const bf16_t*)W1T; a.x = x; a.font = font;
+    a.ldd = ldd; a.ldh = ldh; a.B = B; a.N1 = N1; a.vocab = vocab; a.n_fonts = n_fonts;
+    a.CS = afr_glyph_l1_bwd_fused_split(B, N1); a.ncols = N1 / a.CS;
+    a.slabs = slabs; a.slab_stride = afr_glyph_l1_bwd_fused_slab_floats(B, N1, vocab, n_fonts);
+    a.o_b = a.ncols * bf16k::L1_E; a.o_tab = a.o_b + a.ncols;
+    const size_t lds = (size_t)(a.ncols / 128 + 1) * bf16k::SUB + 2 * bf16k::L1_R * sizeof(int);
+    static size_t set[16];
+    int dev = 0;
+    if (lds > 48 * 1024 && hipGetDevice(&dev) == hipSuccess && (dev < 0 || dev >= 16 || set[dev] < lds)) {
+        hipError_t e = hipFuncSetAttribute((const void*)bf16k::glyph_l1_bwd_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        if (dev >= 0 && dev < 16) set[dev] = lds;
+    }
+    hipLaunchKernelGGL(bf16k::glyph_l1_bwd_fused_kernel, dim3(afr_glyph_l1_bwd_fused_blocks(B, N1)), dim3(512), lds, s, a);
     return hipGetLastError();
 }

@@ -62,7 +62,9 @@ typedef struct afr_config {
                             bit 2: small one-hidden-layer glyph nets through the generic per-layer kernels instead of
                             the fused whole-step kernel of afr_train_step (A/B measurements, parity cross-checks)
                             bit 3: OPT IN to in-launch split-K (afr_op_gemm_fix) for the sheet model's fc_output products
-                            that have no fused loss / optimizer tail (today: the input gradient)                        */
+                            that have no fused loss / optimizer tail (today: the input gradient)
+                            bit 4: the glyph nets' folded first layer backward through the weight-gradient GEMM + post-pass
+                            instead of the fused kernel (A/B measurements, parity cross-checks)                          */
 } afr_config;
 
 typedef struct afr_plan afr_plan;

@@ -86,13 +86,13 @@ def test_operands_of_2gib_or_more_are_rejected_not_silently_zero_filled():
 
 
 def test_grouped_reduce_refuses_more_segments_than_it_can_hold():
-    """afr_rtable_add used to drop segment 25 silently (a gradient would have gone missing); now it is an error."""
+    """afr_rtable_add used to drop the segment past its capacity silently (a gradient would have gone missing); now it is an error."""
     from ai_font_renderer_amd import _lib
     lib = _lib.lib()
-    n = 25
+    n = 33
     ptrs = (C.c_void_p * n)(*[0x1000] * n)
     ns = (C.c_int * n)(*[2] * n)
     st = (C.c_int64 * n)(*[64] * n)
     ln = (C.c_int64 * n)(*[64] * n)
     assert lib.afr_op_reduce_group(n, ptrs, ptrs, ns, st, ln, None) == -1      # AFR_EINVAL
-    assert b"at most 24" in lib.afr_last_error()
+    assert b"at most 32" in lib.afr_last_error()

@@ -200,6 +200,32 @@ def test_in_launch_splitk_gemm(M, N, K, head, sk, ak, bk):
     assert float((outs[0].double() - ref * (aux > 0)).abs().max()) < 1e-2 * scale
 
 
+@pytest.mark.parametrize("cfgkw,B,flags", [
+    (dict(hidden=(1024, 1024), out_h=32, out_w=32, n_fonts=2), 8192, 0),     # C3: 128 row blocks x 2 column ranges
+    (dict(hidden=(1024, 512), out_h=16, out_w=16, n_fonts=2), 1000, 0),      # ragged last block, 4 column ranges
+    (dict(hidden=(256,), out_h=16, out_w=16, n_fonts=0), 4096, 4),           # C2's net through the per-layer kernels, no fonts
+])
+def test_fused_first_layer_backward_matches_the_gemm_path(cfgkw, B, flags):
+    """glyph_l1_bwd_fused_kernel (bf16 mode) against the path it replaces (config.reserved bit 4: widened weight-gradient
+    GEMM + post-pass): dW1 / db1 take the same bf16 operands (f32 sums in another order); the embedding-row gradients
+    differ by the bf16 rounding of W1 and dh0 on the fused side.  Bitwise reproducible."""
+    cfg = GlyphConfig(**cfgkw)
+    x, font, tu8 = glyph_inputs(cfg, B)
+    xt, tt = torch.from_numpy(x), torch.from_numpy(tu8)
+    ft = torch.from_numpy(font) if cfg.n_fonts else None
+    got = {}
+    for fl in (flags, flags | 16):
+        eng = _engine(cfg, dtype="bf16", max_batch=B, flags=fl)
+        eng.train_step(xt, tt, font=ft, do_step=False)
+        g = {k: v.clone() for k, v in eng.grads.items()}
+        eng.train_step(xt, tt, font=ft, do_step=False)
+        assert all(torch.equal(g[k], v) for k, v in eng.grads.items()), fl
+        got[fl] = g
+    for k, ref in got[flags | 16].items():
+        rel = float((got[flags][k] - ref).norm() / ref.norm().clamp_min(1e-20))
+        assert rel < (2e-2 if "embedding" in k else 2e-3), (k, rel)
+
+
 # ----------------------------------------------------------------------------- bit-exact gather (north star)
 @pytest.mark.parametrize("cfgkw,B,xmax", [
     (dict(hidden=(1024, 1024), out_h=32, out_w=32, n_fonts=2), 8192, None),       # C3: folded first layer (table gather)

@@ -53,6 +53,14 @@ def fused1_eligible(cfg):
     return E % 32 == 0 and E <= 64 and N1 % 64 == 0 and N1 <= 256 and P % 64 == 0 and P <= 256 and cfg.vocab + cfg.n_fonts <= 264
 
 
+def l1_bwd_fused_eligible(cfg):
+    """Mirror of afr_glyph_l1_bwd_fused_eligible (csrc/gemm.hip): folded first layers whose backward is ONE kernel in bf16 mode."""
+    if getattr(cfg, "kind", "") != "glyph" or len(cfg.hidden) == 0:
+        return False
+    N1 = cfg.hidden[0]
+    return cfg.embed_dim == 32 and N1 % 128 == 0 and 256 <= N1 <= 1024 and cfg.vocab + cfg.n_fonts <= 144
+
+
 def engine_rounding(cfg, dtype, train_step=False):
     """Rounding hook for the oracle (oracle.linear_fwd/dw/dx sites) that mimics where the HIP engine's bf16 mode
     rounds to bfloat16.  This is knowledge about the IMPLEMENTATION UNDER TEST and lives with its tests; the oracle
@@ -62,7 +70,9 @@ def engine_rounding(cfg, dtype, train_step=False):
     epilogues are f32, stored results are bf16.  Exception -- the glyph model's FOLDED first layer (csrc/elementwise.hip
     glyph_table/l1 kernels, used when 0 < hidden layers and K0 = E + vocab + fonts <= 512 and E <= 128): fc1 is evaluated
     from the f32 tables and f32 W1 (only its result h1 is rounded), and its input gradient is folded into f32 table-row
-    sums (no rounded d0, f32 W1); the stored h0' that feeds dW1 IS bf16.
+    sums (no rounded d0, f32 W1); the stored h0' that feeds dW1 IS bf16.  Where the fused first-layer backward applies
+    (glyph_l1_bwd_fused_kernel: E = 32, N1 a multiple of 128 in 256..1024) the input gradient dh0 = d1 . W1 takes the bf16
+    W1 and is itself rounded to bf16 on its way into the one-hot scatter product.
     train_step=True on a net afr_train_step runs as one fused kernel (csrc/glyph_fused.hip): every product takes bf16
     operands (h0, W1 included), the embedding-row gradient dh0 too (it feeds the one-hot scatter product)."""
     if dtype != "bf16":
@@ -73,6 +83,8 @@ def engine_rounding(cfg, dtype, train_step=False):
         k0 = cfg.embed_dim + (cfg.vocab + cfg.n_fonts + 7) // 8 * 8
         folded = k0 <= 512 and cfg.embed_dim <= 128
     unrounded = {"fc1.fwd.x", "fc1.fwd.w", "fc1.dx.w", "fc1.dx.y"} if folded else set()
+    if folded and l1_bwd_fused_eligible(cfg):
+        unrounded = {"fc1.fwd.x", "fc1.fwd.w"}
     if train_step and fused1_eligible(cfg):
         unrounded = set()
 
