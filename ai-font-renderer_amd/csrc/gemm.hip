@@ -1153,6 +1153,25 @@ __global__ __launch_bounds__(512) void glyph_l1_bwd_fused_kernel(L1BwdArgs a) {
     int* ids = reinterpret_cast<int*>(sm + (NS + 1) * SUB);  // [64] codes, [64] vocab + font id (or -1)
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)sm;
     float* slab = a.slabs + (size_t)blockIdx.x * a.slab_stride;
+#ifdef AFR_L1F_DEBUG
+    unsigned long long ts_[8]; int nts_ = 0;
+#define L1STAMP() do { __syncthreads(); ts_[nts_++] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define L1STAMP() do { } while (0)
+#endif
+    // this wave's W1^T operands of the dh0 product (16 bytes per lane and k-step, <= 32 k-steps): independent of the staging
+    // below, so they are requested first and arrive under it
+    constexpr int L1_MAXKS = 32;
+    bf16x8 wv[L1_MAXKS];
+    {
+        const int erow = (wave & 1) * 16 + r;
+        const bf16_t* wrow = a.W1T + (size_t)erow * a.N1 + n_lo + 8 * q;
+        const int nks = a.ncols >> 5;
+#pragma unroll
+        for (int j = 0; j < L1_MAXKS; ++j)
+            if (j < nks) wv[j] = *reinterpret_cast<const bf16x8*>(wrow + j * 32);
+    }
+    L1STAMP();
     {
         const i32x4 rD = make_rsrc(a.d1), rH = make_rsrc(a.h0);
         const int pieces = (NS + 1) * 16;
@@ -1175,24 +1194,22 @@ __global__ __launch_bounds__(512) void glyph_l1_bwd_fused_kernel(L1BwdArgs a) {
         }
         __syncthreads();
     }
+    L1STAMP();
     // ---- dh0 tile of this wave: glyph rows (wave>>1)*16.., embedding columns (wave&1)*16..; reduction over all N1
     f32x4 dh0 = {0.f, 0.f, 0.f, 0.f};
     {
-        const int brow = (wave >> 1) * 16 + r, erow = (wave & 1) * 16 + r;
-        const bf16_t* wrow = a.W1T + (size_t)erow * a.N1 + n_lo + 8 * q;
+        const int brow = (wave >> 1) * 16 + r;
         const int nks = a.ncols >> 5;
-        for (int k0 = 0; k0 < nks; k0 += 4) {                // ncols is a multiple of 128: whole groups of 4 k-steps
-            bf16x8 wv[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) wv[j] = *reinterpret_cast<const bf16x8*>(wrow + (k0 + j) * 32);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int n = (k0 + j) * 32 + 8 * q, xx = n & 127;
+        for (int j = 0; j < L1_MAXKS; ++j) {
+            if (j < nks) {
+                const int n = j * 32 + 8 * q, xx = n & 127;
                 const bf16x8 av = *reinterpret_cast<const bf16x8*>(Dimg + (n >> 7) * SUB + brow * 256 + (((xx >> 4) ^ fswz(brow)) << 5) + (xx & 15) * 2);
                 dh0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, wv[j], dh0, 0, 0, 0);
             }
         }
     }
+    L1STAMP();
     // ---- dW1 / db1: output tiles [16 n][48 e'] (e' = 32: the ones column), reduction over the block's 64 glyphs
     {
         bf16x8 hf[3][2];
@@ -1216,6 +1233,7 @@ __global__ __launch_bounds__(512) void glyph_l1_bwd_fused_kernel(L1BwdArgs a) {
             if (q == 0) slab[a.o_b + n] = acc[2][0];
         }
     }
+    L1STAMP();
     __syncthreads();                                         // every read of the d1 / h0 images is done: the area is reused
     // ---- embedding_dense_backward as one more product (as glyph1_step_kernel): dh0^T [E][64] and the one-hot image [VT][64]
     bf16_t* dh0T = reinterpret_cast<bf16_t*>(sm);
@@ -1244,6 +1262,10 @@ __global__ __launch_bounds__(512) void glyph_l1_bwd_fused_kernel(L1BwdArgs a) {
         const int v = vt * 16 + r;
         if (v < rows_tot) *reinterpret_cast<f32x4*>(slab + a.o_tab + (size_t)v * L1_E + et * 16 + 4 * q) = acc;
     }
+    L1STAMP();
+#ifdef AFR_L1F_DEBUG
+    if (blockIdx.x == 5 && tid == 0) { printf("l1f phases (us):"); for (int i = 1; i < nts_; ++i) printf(" %.2f", (double)(ts_[i] - ts_[i - 1]) * 0.01); printf("\n"); }
+#endif
 }
 }  // namespace bf16k
 
