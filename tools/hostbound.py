@@ -1,3 +1,5 @@
+#!/usr/bin/env python3
+"""Host issue time vs wall time per training step (is the launch stream host-bound?): python tools/hostbound.py"""
 import sys, time, torch
 sys.path.insert(0, '.')
 from ai_font_renderer_amd import synth
