@@ -68,8 +68,21 @@ __device__ __forceinline__ i32x4 gather16(const float* W, int ld, int x, int kb,
 // start: whatever its epilogue wants from memory (targets, bias) is issued there.  Plain loops, no index arithmetic: a
 // first version that flattened (tile, k-block) pairs with divisions compiled to 5000 instructions per phase and ran
 // instruction-bound.
+// The B operands of a wave's FIRST tile may be requested by the caller ahead of time (first_tile, below: during the previous
+// phase, so that their L2 latency -- 1.5-2 us of every phase otherwise -- is not on the critical path): `pref` != nullptr.
+template <typename T> struct FirstTile { i32x4 v[256 / MM<T>::KB]; };
+template <typename T, class LoadB>
+__device__ __forceinline__ void first_tile(FirstTile<T>& ft, int ntiles, int nkb, int wave, LoadB loadB) {
+    constexpr int NKB = 256 / MM<T>::KB;
+    if (wave < ntiles) {
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb)
+            if (kb < nkb) ft.v[kb] = loadB(wave, kb);
+    }
+}
 template <typename T, int MT, int NW, class LoadB, class Pre, class Epi>
-__device__ __forceinline__ void rows_times_global(const T* A, int lda, int ntiles, int nkb, int wave, int r, int q, LoadB loadB, Pre pre, Epi epi) {
+__device__ __forceinline__ void rows_times_global(const T* A, int lda, int ntiles, int nkb, int wave, int r, int q, LoadB loadB, Pre pre, Epi epi,
+                                                  const FirstTile<T>* pref = nullptr) {
     constexpr int NKB = 256 / MM<T>::KB;             // K <= 256
     i32x4 cur[NKB], nxt[NKB];
     auto fetch = [&](i32x4 (&dst)[NKB], int nt) {
@@ -77,7 +90,10 @@ __device__ __forceinline__ void rows_times_global(const T* A, int lda, int ntile
         for (int kb = 0; kb < NKB; ++kb)
             if (kb < nkb) dst[kb] = loadB(nt, kb);
     };
-    if (wave < ntiles) fetch(cur, wave);
+    if (pref) {
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) cur[kb] = pref->v[kb];
+    } else if (wave < ntiles) fetch(cur, wave);
     for (int nt = wave; nt < ntiles; nt += NW) {
         if (nt + NW < ntiles) fetch(nxt, nt + NW);
         pre(nt);
@@ -94,6 +110,45 @@ __device__ __forceinline__ void rows_times_global(const T* A, int lda, int ntile
         epi(nt, acc);
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb) cur[kb] = nxt[kb];
+    }
+}
+// The same loop with the wave's (at most TPW) tiles unrolled: pre / epi get the tile's ordinal `it` as a compile-time value, so a
+// phase can keep per-tile state it requested long before (the loss phase: every target of the wave's tiles, asked for at
+// kernel entry) in registers.
+template <typename T, int MT, int NW, int TPW, class LoadB, class Pre, class Epi>
+__device__ __forceinline__ void rows_times_global_u(const T* A, int lda, int ntiles, int nkb, int wave, int r, int q, LoadB loadB, Pre pre, Epi epi,
+                                                    const FirstTile<T>* pref = nullptr) {
+    constexpr int NKB = 256 / MM<T>::KB;
+    i32x4 cur[NKB], nxt[NKB];
+    auto fetch = [&](i32x4 (&dst)[NKB], int nt) {
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb)
+            if (kb < nkb) dst[kb] = loadB(nt, kb);
+    };
+    if (pref) {
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) cur[kb] = pref->v[kb];
+    } else if (wave < ntiles) fetch(cur, wave);
+#pragma unroll
+    for (int it = 0; it < TPW; ++it) {
+        const int nt = wave + it * NW;
+        if (nt < ntiles) {
+            if (nt + NW < ntiles) fetch(nxt, nt + NW);
+            pre(nt, it);
+            f32x4 acc[MT];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb) {
+                if (kb < nkb) {
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) MM<T>::mma(acc[m], ld16(A, lda, m * 16 + r, kb, q), cur[kb]);
+                }
+            }
+            epi(nt, it, acc);
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb) cur[kb] = nxt[kb];
+        }
     }
 }
 }  // namespace
@@ -122,6 +177,24 @@ __global__ __launch_bounds__(MM<T>::NTH) void glyph1_step_kernel(Glyph1Args a) {
     T* duT = du + R * ldP;
     const int b0 = blockIdx.x * R;
     const int nb = min(R, a.B - b0);
+    // every target this wave's loss tiles will need (P <= 256: at most TPW tiles of MT x 4 pixels per lane), requested now:
+    // they arrive under the gather and fc1 (asked for when a tile's MFMAs start, each tile waited ~1.5 us for them)
+    constexpr int TPW = 16 / NW;
+    float tv[TPW][MT][4];
+#pragma unroll
+    for (int it = 0; it < TPW; ++it) {
+        const int pcol = (wave + it * NW) * 16 + r;
+        if (pcol < P) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const size_t ti = (size_t)(b0 + min(m * 16 + 4 * q + i, nb - 1)) * P + pcol;
+                    if constexpr (TU8) tv[it][m][i] = __builtin_bit_cast(float, (unsigned)reinterpret_cast<const uint8_t*>(a.target)[ti]);
+                    else tv[it][m][i] = reinterpret_cast<const float*>(a.target)[ti];
+                }
+        }
+    }
 #ifdef AFR_G1_DEBUG
     unsigned long long tstamp[12]; int nst = 0;
 #define G1STAMP() do { __syncthreads(); tstamp[nst++] = __builtin_amdgcn_s_memrealtime(); } while (0)
@@ -131,6 +204,13 @@ __global__ __launch_bounds__(MM<T>::NTH) void glyph1_step_kernel(Glyph1Args a) {
     G1STAMP();
     float* slab = a.slabs + (size_t)blockIdx.x * a.slab_stride;
 
+    const T* W1 = reinterpret_cast<const T*>(a.W1);
+    const T* W2 = reinterpret_cast<const T*>(a.W2);
+    auto loadW1 = [&](int nt, int kb) { return ld16(W1, E, nt * 16 + r, kb, q); };
+    auto loadW2 = [&](int nt, int kb) { return ld16(W2, N1, nt * 16 + r, kb, q); };
+    FirstTile<T> ftA, ftB;                               // two in flight at most: the next phase's, and the one being consumed
+    constexpr bool PF = sizeof(T) == 2;                  // f32 operands are 4x the registers per tile: no room to run ahead
+    if constexpr (PF) first_tile<T>(ftA, N1 / 16, E / KB, wave, loadW1);   // fc1's first tile: requested before the codes are even read
     // ---- codes (index check as glyph_embed_kernel: out of range sets the error word and is clamped) and the gather
     if (tid < R) {
         long long xi = tid < nb ? a.x[b0 + tid] : 0, fi = (tid < nb && a.n_fonts > 0 && a.font) ? a.font[b0 + tid] : 0;
@@ -150,8 +230,6 @@ __global__ __launch_bounds__(MM<T>::NTH) void glyph1_step_kernel(Glyph1Args a) {
     }
     __syncthreads();
 
-    const T* W1 = reinterpret_cast<const T*>(a.W1);
-    const T* W2 = reinterpret_cast<const T*>(a.W2);
     // store one 16x16 accumulator tile (rows m0 + 4q + i, column n0 + r) in both orientations
     auto put_both = [&](T* rowm, int ldr, T* colm, int ldc, int m0, int n0, const float (&v)[4]) {
 #pragma unroll
@@ -163,8 +241,8 @@ __global__ __launch_bounds__(MM<T>::NTH) void glyph1_step_kernel(Glyph1Args a) {
 
     // ---- pre1 = h0 . W1^T + b1 ; h1 = relu(pre1)            wave w owns column tiles w, w+4, ...
     float bias_v = 0.f;
-    rows_times_global<T, MT, NW>(h0, ldE, N1 / 16, E / KB, wave, r, q,
-        [&](int nt, int kb) { return ld16(W1, E, nt * 16 + r, kb, q); },
+    if constexpr (PF) first_tile<T>(ftB, P / 16, N1 / KB, wave, loadW2);   // fc_output's first tile arrives under fc1
+    rows_times_global<T, MT, NW>(h0, ldE, N1 / 16, E / KB, wave, r, q, loadW1,
         [&](int nt) { bias_v = a.b1[nt * 16 + r]; },
         [&](int nt, const f32x4 (&acc)[MT]) {
             const float bias = bias_v;
@@ -175,32 +253,16 @@ __global__ __launch_bounds__(MM<T>::NTH) void glyph1_step_kernel(Glyph1Args a) {
                 for (int i = 0; i < 4; ++i) v[i] = fmaxf(acc[m][i] + bias, 0.f);
                 put_both(h1, ldN, h1T, ldR, m * 16, nt * 16, v);
             }
-        });
+        }, PF ? &ftA : nullptr);
     __syncthreads();
 
     G1STAMP();   // 1: gather + P1
     // ---- u = h1 . W2^T + b2 ; clamp, MSE, du (rows past the batch contribute nothing)
     float lsum = 0.f;
     const float g2 = 2.f * a.inv_n;
-    // a tile's targets (MT x 4 per lane) are fetched when its MFMAs start, all at once and without branches (fetched one
-    // by one inside the epilogue, each behind its own wait and a per-element dtype branch, they were half of the kernel)
-    float tv[MT][4];
-    rows_times_global<T, MT, NW>(h1, ldN, P / 16, N1 / KB, wave, r, q,
-        [&](int nt, int kb) { return ld16(W2, N1, nt * 16 + r, kb, q); },
-        [&](int nt) {
-            const int pcol = nt * 16 + r;
-            bias_v = a.b2[pcol];
-#pragma unroll
-            for (int m = 0; m < MT; ++m)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const size_t ti = (size_t)(b0 + min(m * 16 + 4 * q + i, nb - 1)) * P + pcol;
-                    if constexpr (TU8) tv[m][i] = __builtin_bit_cast(float, (unsigned)reinterpret_cast<const uint8_t*>(a.target)[ti]);
-                    else tv[m][i] = reinterpret_cast<const float*>(a.target)[ti];
-                }
-        },
-        [&](int nt, const f32x4 (&acc)[MT]) {
-            const int pcol = nt * 16 + r;
+    rows_times_global_u<T, MT, NW, TPW>(h1, ldN, P / 16, N1 / KB, wave, r, q, loadW2,
+        [&](int nt, int) { bias_v = a.b2[nt * 16 + r]; },
+        [&](int nt, int it, const f32x4 (&acc)[MT]) {
             const float bias = bias_v;
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
@@ -210,7 +272,7 @@ __global__ __launch_bounds__(MM<T>::NTH) void glyph1_step_kernel(Glyph1Args a) {
                     const int row = m * 16 + 4 * q + i;
                     float u = acc[m][i] + bias;
                     if constexpr (sizeof(T) == 2) u = (float)(bf16_t)u;          // the value the unfused path stores
-                    const float t = TU8 ? lut[__builtin_bit_cast(unsigned, tv[m][i])] : tv[m][i];
+                    const float t = TU8 ? lut[__builtin_bit_cast(unsigned, tv[it][m][i])] : tv[it][m][i];
                     const float diff = fminf(fmaxf(u, 0.f), 1.f) - t;
                     const bool live = row < nb;
                     lsum += live ? diff * diff : 0.f;
@@ -218,9 +280,16 @@ __global__ __launch_bounds__(MM<T>::NTH) void glyph1_step_kernel(Glyph1Args a) {
                 }
                 put_both(du, ldP, duT, ldR, m * 16, nt * 16, v);
             }
-        });
+        }, PF ? &ftB : nullptr);
     __syncthreads();
     G1STAMP();   // 2: P2 + loss
+    // dh1's first W2^T tile is requested now and arrives under the dW2 phase (which reads LDS only)
+    const T* W2T = reinterpret_cast<const T*>(a.W2T);
+    auto loadW2T = [&](int nt, int kb) {
+        if constexpr (sizeof(T) == 4) return gather16(reinterpret_cast<const float*>(a.W2T), N1, nt * 16 + r, kb, q);
+        else return ld16(W2T, P, nt * 16 + r, kb, q);
+    };
+    if constexpr (PF) first_tile<T>(ftA, N1 / 16, P / KB, wave, loadW2T);
 
     // ---- dW2[p][k] = sum_b du[b][p] h1[b][k]  (+ db2): wave w owns p tiles w, w+4, ...; 4 k tiles at a time
     // (operands swapped: the tile comes out as [k][p], so a lane holds 4 consecutive k of one row p -> one 16-byte store)
@@ -249,12 +318,7 @@ __global__ __launch_bounds__(MM<T>::NTH) void glyph1_step_kernel(Glyph1Args a) {
     G1STAMP();   // 3: dW2 + db2
 
     // ---- dh1 = du . W2 ; dpre1 = dh1 * [h1 > 0], written over h1 / h1T (each element is read and rewritten by its owner only)
-    const T* W2T = reinterpret_cast<const T*>(a.W2T);
-    rows_times_global<T, MT, NW>(du, ldP, N1 / 16, P / KB, wave, r, q,
-        [&](int nt, int kb) {
-            if constexpr (sizeof(T) == 4) return gather16(reinterpret_cast<const float*>(a.W2T), N1, nt * 16 + r, kb, q);
-            else return ld16(W2T, P, nt * 16 + r, kb, q);
-        },
+    rows_times_global<T, MT, NW>(du, ldP, N1 / 16, P / KB, wave, r, q, loadW2T,
         [](int) {},
         [&](int nt, const f32x4 (&acc)[MT]) {
 #pragma unroll
@@ -267,7 +331,7 @@ __global__ __launch_bounds__(MM<T>::NTH) void glyph1_step_kernel(Glyph1Args a) {
                 }
                 put_both(h1, ldN, h1T, ldR, m * 16, nt * 16, v);
             }
-        });
+        }, PF ? &ftA : nullptr);
     __syncthreads();
     G1STAMP();   // 4: dh1
 
