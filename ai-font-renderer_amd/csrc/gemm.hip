@@ -344,7 +344,7 @@ __device__ unsigned long long* g_gemm_stamps = nullptr;
 // wave's own 16 KiB of LDS.  Shared by the 256x128 / 128x128 kernels (one call) and the 256x256 kernel (two calls).
 template <int ALAY, int BLAY, int WM>
 __device__ __forceinline__ void wave_epilogue(const GemmParams& p, const f32x4 (&acc)[4][4], const int mb, const int nb0, const int z,
-                                              float* Wt, const int lane, float& lsum) {
+                                              float* Wt, const int lane, float& lsum, const float* lut255 = nullptr) {
     // Epilogue through LDS: the MFMA accumulators hold 4 consecutive n of 16 different rows per lane-group, which as
     // direct stores would be 32-byte pieces.  Each wave parks its 64x64 f32 tile in its own 16 KiB of LDS (16-B chunks
     // XOR-swizzled by row: conflict-free both ways) and streams it out row-contiguous: 8 lanes x 8 values = one 64-col
@@ -469,8 +469,13 @@ __device__ __forceinline__ void wave_epilogue(const GemmParams& p, const f32x4 (
             const size_t ti = (size_t)m * p.N + n;
             if (p.mse_target_dtype == AFR_TARGET_U8) {
                 const uint2 w = tu8[ps];
+                if (lut255) {                          // k / 255.0f looked up (the block computed the 256 quotients once): same values
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { t[r] = (float)((w.x >> (8 * r)) & 0xFF) / 255.0f; t[4 + r] = (float)((w.y >> (8 * r)) & 0xFF) / 255.0f; }
+                    for (int r = 0; r < 4; ++r) { t[r] = lut255[(w.x >> (8 * r)) & 0xFF]; t[4 + r] = lut255[(w.y >> (8 * r)) & 0xFF]; }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { t[r] = (float)((w.x >> (8 * r)) & 0xFF) / 255.0f; t[4 + r] = (float)((w.y >> (8 * r)) & 0xFF) / 255.0f; }
+                }
             } else {
                 const float4 w0 = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.mse_target) + ti);
                 const float4 w1 = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.mse_target) + ti + 4);
@@ -794,7 +799,16 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmParams& p, const int bi
     }
     const bool mse = p.mse_target != nullptr;
     float lsum = 0.f;
-    wave_epilogue<ALAY, BLAY, WM>(p, acc, m0 + wm * 64, n0 + wn * 64, z, reinterpret_cast<float*>(smem) + wave * 4096, lane, lsum);
+    // uint8 targets of the fused loss are pixel / 255.0f (helpers.py:121): 256 true divisions per block instead of one per
+    // output element (the 8-wave kernel's LDS has room behind the waves' staging tiles)
+    const float* lut255 = nullptr;
+    if (WM == 4 && mse && p.mse_target_dtype == AFR_TARGET_U8) {
+        float* l = reinterpret_cast<float*>(smem) + NW * 4096;
+        if (tid < 256) l[tid] = (float)tid / 255.0f;
+        __syncthreads();
+        lut255 = l;
+    }
+    wave_epilogue<ALAY, BLAY, WM>(p, acc, m0 + wm * 64, n0 + wn * 64, z, reinterpret_cast<float*>(smem) + wave * 4096, lane, lsum, lut255);
     if (mse) {
         float* red = reinterpret_cast<float*>(smem);
         __syncthreads();                       // every wave is done with its staging tile
