@@ -425,52 +425,54 @@ __global__ __launch_bounds__(256) void glyph_l1_fwd_kernel(const float* __restri
                                                            const int64_t* __restrict__ x, const int64_t* __restrict__ font,
                                                            int B, int E, int N1, int vocab, int n_fonts, int K0,
                                                            T* __restrict__ h0, T* __restrict__ h1, uint32_t* err_flag) {
-    const int c1 = N1 >> 3, c0 = K0 >> 3, per_row = c1 + c0;      // 8-column chunks of h1, then of h0'
-    const long long total = (long long)B * per_row;
-    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        const int b = (int)(i / per_row), c = (int)(i % per_row);
-        long long xi = x[b];
-        if (xi < 0 || xi >= vocab) { if (c == 0) atomicOr(err_flag, 1u); xi = min(max(xi, 0ll), (long long)vocab - 1); }
-        long long fi = 0;
-        if (n_fonts > 0) {
-            fi = font ? font[b] : 0;
-            if (fi < 0 || fi >= n_fonts) { if (c == 0) atomicOr(err_flag, 1u); fi = min(max(fi, 0ll), (long long)n_fonts - 1); }
-        }
+    // one glyph per threadIdx.y, its 8-column chunks of h1 (N1/8) and then of h0' (K0/8) strided over threadIdx.x: no index
+    // division (a flat index over B x (N1 + K0)/8 items cost a 64-bit divide + modulo by a runtime divisor per item)
+    const int c1 = N1 >> 3, c0 = K0 >> 3;
+    const int b = blockIdx.x * blockDim.y + threadIdx.y;
+    if (b >= B) return;
+    long long xi = x[b];
+    if (xi < 0 || xi >= vocab) { if (threadIdx.x == 0) atomicOr(err_flag, 1u); xi = min(max(xi, 0ll), (long long)vocab - 1); }
+    long long fi = 0;
+    if (n_fonts > 0) {
+        fi = font ? font[b] : 0;
+        if (fi < 0 || fi >= n_fonts) { if (threadIdx.x == 0) atomicOr(err_flag, 1u); fi = min(max(fi, 0ll), (long long)n_fonts - 1); }
+    }
+    const float* trow_c = table + (size_t)xi * N1;
+    const float* trow_f = table + (size_t)(vocab + fi) * N1;
+    for (int c = threadIdx.x; c < c1; c += blockDim.x) {
         float v[8];
-        if (c < c1) {
-            const int n = 8 * c;
-            const float* tc = table + (size_t)xi * N1 + n;
-            const float4 a0 = *reinterpret_cast<const float4*>(tc), a1 = *reinterpret_cast<const float4*>(tc + 4);
-            const float4 g0 = *reinterpret_cast<const float4*>(b1 + n), g1 = *reinterpret_cast<const float4*>(b1 + n + 4);
-            v[0] = a0.x + g0.x; v[1] = a0.y + g0.y; v[2] = a0.z + g0.z; v[3] = a0.w + g0.w;
-            v[4] = a1.x + g1.x; v[5] = a1.y + g1.y; v[6] = a1.z + g1.z; v[7] = a1.w + g1.w;
+        const int n = 8 * c;
+        const float4 a0 = *reinterpret_cast<const float4*>(trow_c + n), a1 = *reinterpret_cast<const float4*>(trow_c + n + 4);
+        const float4 g0 = *reinterpret_cast<const float4*>(b1 + n), g1 = *reinterpret_cast<const float4*>(b1 + n + 4);
+        v[0] = a0.x + g0.x; v[1] = a0.y + g0.y; v[2] = a0.z + g0.z; v[3] = a0.w + g0.w;
+        v[4] = a1.x + g1.x; v[5] = a1.y + g1.y; v[6] = a1.z + g1.z; v[7] = a1.w + g1.w;
+        if (n_fonts > 0) {
+            const float4 f0 = *reinterpret_cast<const float4*>(trow_f + n), f1 = *reinterpret_cast<const float4*>(trow_f + n + 4);
+            v[0] += f0.x; v[1] += f0.y; v[2] += f0.z; v[3] += f0.w; v[4] += f1.x; v[5] += f1.y; v[6] += f1.z; v[7] += f1.w;
+        }
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] = fmaxf(v[r], 0.f);
+        store8(h1 + (size_t)b * N1 + n, v);
+    }
+    for (int c = threadIdx.x; c < c0; c += blockDim.x) {
+        // h0' = [h0 | one-hot of x_b | one-hot of vocab + f_b | zero pad]
+        float v[8];
+        const int k0 = 8 * c;
+        if (k0 < E) {                                     // E % 8 == 0: a chunk is all h0 or all one-hot
+            const float* e = emb + (size_t)xi * E + k0;
+            const float4 a0 = *reinterpret_cast<const float4*>(e), a1 = *reinterpret_cast<const float4*>(e + 4);
+            v[0] = a0.x; v[1] = a0.y; v[2] = a0.z; v[3] = a0.w; v[4] = a1.x; v[5] = a1.y; v[6] = a1.z; v[7] = a1.w;
             if (n_fonts > 0) {
-                const float* tf = table + (size_t)(vocab + fi) * N1 + n;
-                const float4 f0 = *reinterpret_cast<const float4*>(tf), f1 = *reinterpret_cast<const float4*>(tf + 4);
+                const float* f = femb + (size_t)fi * E + k0;
+                const float4 f0 = *reinterpret_cast<const float4*>(f), f1 = *reinterpret_cast<const float4*>(f + 4);
                 v[0] += f0.x; v[1] += f0.y; v[2] += f0.z; v[3] += f0.w; v[4] += f1.x; v[5] += f1.y; v[6] += f1.z; v[7] += f1.w;
             }
-#pragma unroll
-            for (int r = 0; r < 8; ++r) v[r] = fmaxf(v[r], 0.f);
-            store8(h1 + (size_t)b * N1 + n, v);
         } else {
-            // h0' = [h0 | one-hot of x_b | one-hot of vocab + f_b | zero pad]
-            const int k0 = 8 * (c - c1);
-            if (k0 < E) {                                     // E % 8 == 0: a chunk is all h0 or all one-hot
-                const float* e = emb + (size_t)xi * E + k0;
-                const float4 a0 = *reinterpret_cast<const float4*>(e), a1 = *reinterpret_cast<const float4*>(e + 4);
-                v[0] = a0.x; v[1] = a0.y; v[2] = a0.z; v[3] = a0.w; v[4] = a1.x; v[5] = a1.y; v[6] = a1.z; v[7] = a1.w;
-                if (n_fonts > 0) {
-                    const float* f = femb + (size_t)fi * E + k0;
-                    const float4 f0 = *reinterpret_cast<const float4*>(f), f1 = *reinterpret_cast<const float4*>(f + 4);
-                    v[0] += f0.x; v[1] += f0.y; v[2] += f0.z; v[3] += f0.w; v[4] += f1.x; v[5] += f1.y; v[6] += f1.z; v[7] += f1.w;
-                }
-            } else {
-                const int r0 = k0 - E, hx = (int)xi, hf = n_fonts > 0 ? vocab + (int)fi : -1;
+            const int r0 = k0 - E, hx = (int)xi, hf = n_fonts > 0 ? vocab + (int)fi : -1;
 #pragma unroll
-                for (int r = 0; r < 8; ++r) v[r] = (r0 + r == hx || r0 + r == hf) ? 1.f : 0.f;
-            }
-            store8(h0 + (size_t)b * K0 + k0, v);
+            for (int r = 0; r < 8; ++r) v[r] = (r0 + r == hx || r0 + r == hf) ? 1.f : 0.f;
         }
+        store8(h0 + (size_t)b * K0 + k0, v);
     }
 }
 hipError_t afr_launch_glyph_l1_fwd(int act_dtype, const float* emb, const float* font_emb, const float* W1, const float* b1,
@@ -490,7 +492,10 @@ hipError_t afr_launch_glyph_l1_fwd(int act_dtype, const float* emb, const float*
     }
     hipLaunchKernelGGL(glyph_table_kernel, dim3((rows + GT_ROWS - 1) / GT_ROWS, (N1 + 255) / 256), dim3(256), tlds, s, emb, font_emb,
                        W1, vocab, rows, E, N1, table, (bf16_t*)w1t);
-    dim3 g(grid_for((long long)B * ((N1 + K0) / 8), 256, 8192)), b(256);
+    // threads: x over a glyph's 8-column chunks (a power of two up to 128), y over glyphs; 256 threads per block
+    int tx = 32;
+    while (tx < 128 && tx < N1 / 8) tx *= 2;
+    dim3 b(tx, 256 / tx), g((B + b.y - 1) / b.y);
     if (act_dtype == AFR_BF16)
         hipLaunchKernelGGL(glyph_l1_fwd_kernel<bf16_t>, g, b, 0, s, table, b1, emb, font_emb, x, font, B, E, N1, vocab, n_fonts, K0,
                            (bf16_t*)h0, (bf16_t*)h1, err_flag);
