@@ -10,7 +10,7 @@ R=${1:-r02}
 O=gpurun_out/$R
 mkdir -p $O
 export TMPDIR=/tmp
-B="--steps 100 --warmup 10 --no-extras --no-cpu-baseline"
+B="--steps 100 --warmup 10 --no-extras --no-cpu-baseline --preheat-ms 0"     # no pre-heat forwards in the kernel statistics
 for w in c1 c2 c3 r0; do
   python3 bench.py --workload $w --steps 200 --warmup 20 --table --no-extras > $O/bench_$w.log 2>&1
   echo "bench $w done"
