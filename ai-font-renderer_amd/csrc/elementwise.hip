@@ -366,9 +366,9 @@ hipError_t afr_launch_glyph_embed(int act_dtype, const float* emb, const float* 
 // fc1 (no dropout, no nonlinearity in between), and a batch of thousands of glyphs draws from only vocab + n_fonts
 // distinct rows, so   fc1(h0)[b] = T[x_b] + T[vocab + f_b] + b1   with   T = [Emb; Font] . W1^T   ((vocab+n_fonts) x N1).
 // The table costs (vocab+n_fonts)*N1*E MACs per step instead of B*N1*E, stays in L2, and the layer becomes a gather.
-// table[r][n] = sum_k tab(r)[k] * W1[n][k].  A block stages 256 fc1 rows (coalesced, padded to E+1 in LDS) and 8 table
+// table[r][n] = sum_k tab(r)[k] * W1[n][k].  A block stages 256 fc1 rows (coalesced, padded to E+1 in LDS) and GT_ROWS table
 // rows, one thread per n; grid (ceil(rows/8), ceil(N1/256)).
-constexpr int GT_ROWS = 8;
+constexpr int GT_ROWS = 2;    // rows per block: the kernel is latency bound, more blocks (272 at C3) beat fewer, fatter ones (8: +1.5 us)
 __global__ __launch_bounds__(256) void glyph_table_kernel(const float* __restrict__ emb, const float* __restrict__ femb,
                                                           const float* __restrict__ W1, int vocab, int rows, int E, int N1,
                                                           float* __restrict__ table, bf16_t* __restrict__ w1t) {
