@@ -250,10 +250,24 @@ def adamw_step(p, g, m, v, t, lr=1e-3, beta1=0.9, beta2=0.99, eps=1e-8, wd=5e-4)
     return p, m, v
 
 
+def adamw_step_(p, g, m, v, t, lr=1e-3, beta1=0.9, beta2=0.99, eps=1e-8, wd=5e-4):
+    """The same update IN PLACE, in the operation order of torch/optim/adamw.py's single-tensor path (mul_, lerp_ /
+    mul_.addcmul_, addcdiv_): no temporaries the size of the parameters.  For the CPU-baseline timing (bench.py), where the
+    functional form above spent more time allocating than computing; the parity tests use the functional form."""
+    p.mul_(1.0 - lr * wd)
+    m.lerp_(g, 1.0 - beta1)
+    v.mul_(beta2).addcmul_(g, g, value=1.0 - beta2)
+    bc1 = 1.0 - beta1 ** t
+    bc2 = 1.0 - beta2 ** t
+    denom = (v.sqrt() / math.sqrt(bc2)).add_(eps)
+    p.addcdiv_(m, denom, value=-(lr / bc1))
+    return p, m, v
+
+
 def train_step(P, M, V, t, x, target, cfg, font=None, masks=None, lr=1e-3, beta1=0.9, beta2=0.99,
-               eps=1e-8, wd=5e-4):
+               eps=1e-8, wd=5e-4, inplace=False):
     """zero_grad -> forward -> MSE -> backward -> AdamW (model.py:292-310).  Returns
-    (loss, grads, newP, newM, newV)."""
+    (loss, grads, newP, newM, newV); inplace=True updates P, M, V themselves (adamw_step_)."""
     if cfg.kind == "sheet":
         _, cache = sheet_forward(P, x, cfg, masks)
         loss, du = mse_loss_grad(cache["u"], target)
@@ -262,6 +276,10 @@ def train_step(P, M, V, t, x, target, cfg, font=None, masks=None, lr=1e-3, beta1
         _, cache = glyph_forward(P, x, font, cfg)
         loss, du = mse_loss_grad(cache["u"], target)
         G = glyph_backward(P, cache, du, cfg)
+    if inplace:
+        for k in P:
+            adamw_step_(P[k], G[k], M[k], V[k], t, lr, beta1, beta2, eps, wd)
+        return loss, G, P, M, V
     nP, nM, nV = {}, {}, {}
     for k in P:
         nP[k], nM[k], nV[k] = adamw_step(P[k], G[k], M[k], V[k], t, lr, beta1, beta2, eps, wd)

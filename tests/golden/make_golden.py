@@ -30,6 +30,8 @@ stored.  What is captured:
                   characters, batch 16, dropout off, plateau patience 1, early-stop patience 4, <= 16 epochs; run "a" LR 0.004, run "b" LR 0.03):
                   per-epoch validation loss and learning rate as its scheduler saw them, the train losses it printed, its
                   training_results.txt, and the parameters it ended with
+  cpu_step_times.json  (on request: `make_golden.py cpu_step_times`) step time of the reference's own training step against the
+                  oracle's on the same R0 shapes in this container: the provenance of bench.py's cpu_baseline "port"
   helpers.npz     binary_array_to_image truncation (helpers.py:33), image_to_binary_array (helpers.py:121)
                   on a 24-bit top-down BMP written per generate_font.ts:6-62
 """
@@ -390,6 +392,93 @@ def _train_loop_run(lr_):
             setattr(ref, k, v)
 
 
+def cpu_step_times():
+    """BASELINE.md 3 / bench.py cpu_baseline provenance: the oracle's train step (what bench.py times on the GPU box's host
+    cores as "kind": "port") against the REFERENCE's own step (model.train(); forward; F.mse_loss; backward; AdamW.step --
+    model.py:291-311) on the same shapes, in this container.  Writes tests/golden/cpu_step_times.json."""
+    import json
+    import time
+    sys.path.insert(0, os.path.join(ROOT))
+    from oracle import afr_oracle as oracle
+    out = {"torch": torch.__version__, "threads": torch.get_num_threads(), "cases": []}
+    for B in (64, 256):
+        cfg = WORKLOADS["r0"]["cfg"]
+        strings = synth.dataset_strings(B)
+        x = torch.from_numpy(synth.encode_strings(strings, cfg.max_length))
+        tgt = torch.from_numpy(synth.synth_sheet_targets(B, cfg.sheet_h, cfg.sheet_w, tensor_id=955).astype(np.float32) / 255.0)
+        m = build_ref(cfg)
+        m.train()
+        opt = torch.optim.AdamW(m.parameters(), lr=ref.LEARNING_RATE, weight_decay=ref.WEIGHT_DECAY, betas=(0.9, 0.99))
+
+        def ref_step():
+            opt.zero_grad()
+            o = m(x)
+            loss = F.mse_loss(o, tgt.view(o.shape))
+            loss.backward()
+            opt.step()
+
+        def timed(fn, n):
+            fn()
+            ts = []
+            for _ in range(n):
+                t0 = time.perf_counter(); fn(); ts.append(time.perf_counter() - t0)
+            return float(np.min(ts))                  # the container is shared: the fastest of n is the least disturbed
+        t_ref = timed(ref_step, 7)
+        m.embedding_dropout.p = 0.0; m.dropout1.p = 0.0; m.attention.dropout = 0.0
+        t_ref_nodrop = timed(ref_step, 7)
+        del m, opt
+        P = {k: torch.from_numpy(v) for k, v in synth.make_params(cfg).items()}
+        M = {k: torch.zeros_like(v) for k, v in P.items()}
+        V = {k: torch.zeros_like(v) for k, v in P.items()}
+        masks = {k: torch.from_numpy(v) for k, v in synth.sheet_dropout_masks(cfg, B, cfg.max_length, 42, 1).items()}
+        state = [P, M, V, 0]
+
+        def ora_step():
+            state[3] += 1
+            _, _, state[0], state[1], state[2] = oracle.train_step(state[0], state[1], state[2], state[3], x, tgt, cfg, masks=masks, inplace=True)
+        t_ora = timed(ora_step, 7)
+        out["cases"].append({"workload": "r0", "batch": B, "reference_step_ms": t_ref * 1e3, "reference_step_no_dropout_ms": t_ref_nodrop * 1e3,
+                             "oracle_step_ms": t_ora * 1e3, "oracle_over_reference": t_ora / t_ref})
+        print(out["cases"][-1])
+    # C3 (no class in the reference): the torch.nn twin above stands for "the reference's way of writing it" (nn.Embedding,
+    # nn.Linear, F.mse_loss, autograd, optim.AdamW)
+    cfg = WORKLOADS["c3"]["cfg"]
+    B = WORKLOADS["c3"]["batch"]
+    xg, fg, tg = glyph_inputs(cfg, B)
+    xg, fg = torch.from_numpy(xg), torch.from_numpy(fg)
+    tgt = torch.from_numpy(tg.astype(np.float32) / 255.0)
+    tw = GlyphTwin(cfg)
+    tw.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_params(cfg).items()})
+    opt = torch.optim.AdamW(tw.parameters(), lr=ref.LEARNING_RATE, weight_decay=ref.WEIGHT_DECAY, betas=(0.9, 0.99))
+
+    def twin_step():
+        opt.zero_grad()
+        o = tw(xg, fg)
+        F.mse_loss(o, tgt.view(o.shape)).backward()
+        opt.step()
+
+    def timed2(fn, n):
+        fn()
+        ts = []
+        for _ in range(n):
+            t0 = time.perf_counter(); fn(); ts.append(time.perf_counter() - t0)
+        return float(np.min(ts))
+    t_tw = timed2(twin_step, 9)
+    P = {k: torch.from_numpy(v) for k, v in synth.make_params(cfg).items()}
+    M = {k: torch.zeros_like(v) for k, v in P.items()}
+    V = {k: torch.zeros_like(v) for k, v in P.items()}
+    st = [0]
+
+    def ora3():
+        st[0] += 1
+        oracle.train_step(P, M, V, st[0], xg, tgt.view(B, -1), cfg, font=fg, inplace=True)
+    t_o3 = timed2(ora3, 9)
+    out["cases"].append({"workload": "c3", "batch": B, "reference_step_ms": None, "torch_nn_twin_step_ms": t_tw * 1e3,
+                         "oracle_step_ms": t_o3 * 1e3, "oracle_over_twin": t_o3 / t_tw})
+    print(out["cases"][-1])
+    json.dump(out, open(os.path.join(OUT, "cpu_step_times.json"), "w"), indent=1)
+
+
 def bmp24_topdown(rgb):
     """24-bit BGR top-down BMP bytes in the layout generate_font.ts:6-62 writes."""
     import struct
@@ -428,3 +517,5 @@ if __name__ == "__main__":
     for fn in (glyph_ref1, glyph_twin, glyph_bitmaps, train_loop, mini, helpers_fx, r0):
         if not only or fn.__name__ in only:
             fn()
+    if "cpu_step_times" in only:              # timing, not a parity fixture: only on request
+        cpu_step_times()
