@@ -205,3 +205,17 @@ def test_text_generator_matches_survey_strings():
     assert synth.lcg_text(44) == "YHS IYXCTW TBALZN YHXKESJ CHFW BM"
     lens = [len(synth.lcg_text(42 + i)) for i in range(2000)]
     assert min(lens) >= 10 and max(lens) <= 100
+
+
+def test_inplace_adamw_of_the_cpu_baseline_equals_the_functional_form():
+    """bench.py's cpu_baseline times oracle.train_step(inplace=True); its AdamW must be the same update as adamw_step (which the
+    goldens pin against torch.optim.AdamW) -- equal to f32 rounding (lerp_/addcmul_/addcdiv_ fuse differently)."""
+    import torch
+    g = torch.Generator().manual_seed(3)
+    p, gr = torch.randn(4096, generator=g), torch.randn(4096, generator=g) * 0.1
+    m, v = torch.randn(4096, generator=g) * 0.01, torch.rand(4096, generator=g) * 1e-3
+    for t in (1, 2, 7):
+        want = oracle.adamw_step(p, gr, m, v, t)
+        got = oracle.adamw_step_(p.clone(), gr, m.clone(), v.clone(), t)
+        for a, b in zip(got, want):
+            assert float((a - b).abs().max()) <= 2e-7 * float(b.abs().max()) + 1e-9
