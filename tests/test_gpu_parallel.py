@@ -84,6 +84,36 @@ def test_data_parallel_stepper_over_rccl_world1(schedule, monkeypatch):
         dist.destroy_process_group()
 
 
+def test_c4_per_gpu_shard_through_the_data_parallel_step():
+    """BASELINE configs[3]: the per-GPU shard (C3 net, bf16, 8192 glyphs) through the multi-rank code path (materialised
+    gradients -> RCCL all-reduce -> AdamW kernel) over a world of one: the same parameters as the fused single-GPU step
+    (AdamW inside the slab reduction), bit for bit -- both apply the same adamw_elem to the same ordered slab sums."""
+    import torch.distributed as dist
+    from ai_font_renderer_amd.config import WORKLOADS
+    from ai_font_renderer_amd.engine import Engine
+    from ai_font_renderer_amd.parallel import DataParallelStepper
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", str(29600 + os.getpid() % 300))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        cfg, B = WORKLOADS["c3"]["cfg"], WORKLOADS["c3"]["batch"]
+        x, font, t = glyph_inputs(cfg, B)
+        xt, ft, tt = torch.from_numpy(x).cuda(), torch.from_numpy(font).cuda(), torch.from_numpy(t).cuda()
+        res = []
+        for world in (2, 1):                                  # 2: forced multi-rank path; 1: fused single-GPU step
+            eng = Engine(cfg, dtype="bf16", max_batch=B)
+            eng.load_params(synth.make_params(cfg))
+            st = DataParallelStepper(eng, dist if world > 1 else None, world=world)
+            for _ in range(3):
+                st.step(xt, tt, ft, mean_elems=B * cfg.pixels)
+            res.append((st.global_loss(), eng.flat_params.clone()))
+            del eng
+        assert res[0][0] == res[1][0]
+        assert torch.equal(res[0][1], res[1][1])
+    finally:
+        dist.destroy_process_group()
+
+
 def test_opt_in_bf16_gradient_exchange_tracks_the_exact_exchange(monkeypatch):
     """AFR_DP_GRAD_BF16=1 rounds each rank's gradient to bf16 for the all-reduce (throughput mode only): three steps stay
     within bf16 rounding of the exact-f32 exchange; the f32 engine ignores the switch."""
