@@ -60,6 +60,8 @@ SIGNATURES = {
     "afr_op_gemm": (_i32, [_i32, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "afr_op_gemm_fix_workspace_bytes": (_sz, [_i32, _i32, _i32, _i32]),
     "afr_op_gemm_fix": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _sz, _vp]),
+    "afr_op_gemm_pair_plan": (_i32, [_i32, _i32, _i32, C.POINTER(_i32), C.POINTER(_sz)]),
+    "afr_op_gemm_pair": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _sz, _vp]),
     "afr_op_reduce": (_i32, [_vp, _vp, _i32, _i64, _i64, _f32, _i32, _vp]),
     "afr_op_reduce_group": (_i32, [_i32, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_i32), C.POINTER(_i64), C.POINTER(_i64), _vp]),
     "afr_op_adamw": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _i64, _f32, _vp]),

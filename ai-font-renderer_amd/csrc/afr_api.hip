@@ -85,8 +85,17 @@ struct afr_plan {
     size_t o_w1t = 0, o_w2t = 0, o_slab1 = 0;
     bool l1f = false; size_t o_l1f = 0;   // glyph, bf16: folded first layer's backward in one kernel (slabs [blocks][dW1|db1|dTab])
     size_t o_fix = 0, o_fixcnt = 0; bool have_fix = false;   // in-launch split-K: slice parking area + per-tile arrival counters
+    // bf16 glyph nets: TWO weight shadows.  A fused optimizer step writes every tensor's new bf16 copy into the one that is
+    // not being read (a layer's weight-gradient workgroups update the weights while the same launch's input-gradient
+    // workgroups still read them), and the roles swap when the step is complete.
+    size_t o_shadow2 = 0; int shadow_cur = 0;
+    // hyper-parameters of the optimizer step in progress (afr_train_step): set while backward runs, so that weight-gradient
+    // products with a cooperative split-K tail apply AdamW themselves; adam_done lists the tensors they have updated
+    bool step_on = false; float st_decay = 1.f, st_b1 = 0.f, st_b2 = 0.f, st_eps = 0.f, st_step = 0.f, st_rsqrt_bc2 = 1.f;
+    std::vector<int64_t> adam_done;
     // glyph layer table
-    struct Layer { int N, K; int64_t w_off, b_off; int sk = 1; size_t o_slab_w = 0, o_slab_b = 0; };
+    struct Layer { int N, K; int64_t w_off, b_off; int sk = 1; size_t o_slab_w = 0, o_slab_b = 0;
+                   size_t o_cnt = 0; int n_cnt = 0; unsigned coop_epoch = 0; };   // cooperative split-K: per-tile arrival counters, launches so far
     std::vector<Layer> layers;
     int64_t emb_off = 0, font_off = 0;
     // sheet offsets
@@ -226,7 +235,7 @@ extern "C" int afr_plan_create(const afr_config* c, afr_plan** out) {
         p->layers.push_back(ly);
         p->emb_off = off_of(p, "embedding.weight");
         p->font_off = c->n_fonts > 0 ? off_of(p, "font_embedding.weight") : -1;
-        if (c->dtype == AFR_BF16) p->o_shadow = carve((size_t)p->total * 2);
+        if (c->dtype == AFR_BF16) { p->o_shadow = carve((size_t)p->total * 2); p->o_shadow2 = carve((size_t)p->total * 2); }
         p->o_err = carve(256);
         p->o_loss = carve(((size_t)((B + 127) / 128) * ((Pix + 127) / 128) + 1040) * sizeof(float));
         size_t maxw = (size_t)E, maxn = 0;
@@ -245,7 +254,10 @@ extern "C" int afr_plan_create(const afr_config* c, afr_plan** out) {
             // the folded first layer's weight-gradient GEMM is K0 wide and always lands in slabs (even a single one)
             const int kw = (first && p->k0) ? p->k0 : l.K;
             l.sk = choose_splitk(l.N, kw, (int)B);
-            if (l.sk > 1 || (first && p->k0)) { l.o_slab_w = carve((size_t)l.sk * l.N * kw * sizeof(float)); l.o_slab_b = carve((size_t)l.sk * l.N * sizeof(float)); }
+            // (slab space in whole 256x256 tiles: the cooperative split-K parks register images of full tiles there)
+            const size_t wt = (size_t)((l.N + 255) / 256) * ((kw + 255) / 256);
+            if (l.sk > 1 || (first && p->k0)) { l.o_slab_w = carve((size_t)l.sk * wt * 65536 * sizeof(float)); l.o_slab_b = carve((size_t)l.sk * l.N * sizeof(float)); }
+            l.n_cnt = (int)wt; l.o_cnt = carve(wt * sizeof(unsigned));
             if ((size_t)l.N > maxn) maxn = (size_t)l.N;
             first = false;
         }
@@ -333,6 +345,11 @@ extern "C" int afr_bind(afr_plan* p, float* params, float* grads, float* m, floa
     p->ws = (char*)ws; p->ws_bytes = ws_bytes;
     p->have_du = false;
     p->wT_valid = false;
+    p->shadow_cur = 0; p->step_on = false; p->adam_done.clear();
+    for (auto& l : p->layers) {                          // cooperative split-K: arrival counters and launch count start at zero
+        l.coop_epoch = 0;
+        if (l.n_cnt) { DevGuard dg(dev); HIPCHK(hipMemset(p->ws + l.o_cnt, 0, (size_t)l.n_cnt * sizeof(unsigned))); }
+    }
     if (p->have_fix) {                                   // arrival counters start at zero; the kernels re-arm them
         DevGuard dg(dev);
         HIPCHK(hipMemset(p->ws + p->o_fixcnt, 0, AFR_FIX_MAX_SLICES * sizeof(unsigned)));
@@ -471,14 +488,25 @@ extern "C" int afr_profile_dump(afr_plan* p, char* buf, int cap) {
 // ------------------------------------------------------------------------------------ helpers
 struct FusedLoss { const void* target; int tdtype; int64_t mean_elems; float* loss_accum; };
 struct FusedAdam { float *p, *m, *v; bf16_t* shadow; float decay, b1, b2, eps, step_size, rsqrt_bc2; };
+struct CoopArgs { float* ws; unsigned* cnt; unsigned target; };
+// the bf16 weight shadow the GEMMs read / the one a fused optimizer step writes (the same buffer unless the plan has two)
+static inline bf16_t* shadow_rd(const afr_plan* p) {
+    if (p->cfg.dtype != AFR_BF16) return nullptr;
+    return (bf16_t*)(p->ws + ((p->shadow_cur && p->o_shadow2) ? p->o_shadow2 : p->o_shadow));
+}
+static inline bf16_t* shadow_wr(const afr_plan* p) {
+    if (p->cfg.dtype != AFR_BF16) return nullptr;
+    if (!p->o_shadow2) return (bf16_t*)(p->ws + p->o_shadow);
+    return (bf16_t*)(p->ws + (p->shadow_cur ? p->o_shadow : p->o_shadow2));
+}
 static inline const void* weight_ptr(const afr_plan* p, int64_t off) {
-    if (p->cfg.dtype == AFR_BF16) return p->ws + p->o_shadow + (size_t)off * 2;
+    if (p->cfg.dtype == AFR_BF16) return shadow_rd(p) + off;
     return p->P + off;
 }
 static int run_gemm(afr_plan* p, hipStream_t s, int flags, const void* A, const void* B, void* C, const float* bias,
                     const void* aux, int M, int N, int K, int lda, int ldb, int ldc, int ldaux, int splitk,
                     long long slab_stride, float* colsum = nullptr, long long colsum_stride = 0, const FusedLoss* fl = nullptr,
-                    const FusedAdam* fa = nullptr) {
+                    const FusedAdam* fa = nullptr, const CoopArgs* coop = nullptr) {
     if (p->cfg.dtype == AFR_BF16) {
         const bool ak = flags & AFR_GEMM_A_KSTRIDED, bk = flags & AFR_GEMM_B_KSTRIDED;
         const long long ea = (long long)(ak ? K : M) * lda * 2, ebb = (long long)(bk ? K : N) * ldb * 2;
@@ -490,6 +518,7 @@ static int run_gemm(afr_plan* p, hipStream_t s, int flags, const void* A, const 
         g.ad_decay = fa->decay; g.ad_b1 = fa->b1; g.ad_b2 = fa->b2; g.ad_eps = fa->eps; g.ad_step = fa->step_size; g.ad_rsqrt_bc2 = fa->rsqrt_bc2;
     }
     g.colsum = colsum; g.colsum_stride = colsum_stride;
+    if (coop) { g.coop_ws = coop->ws; g.coop_cnt = coop->cnt; g.coop_target = coop->target; g.err = (uint32_t*)(p->ws + p->o_err); }
     if (fl) {
         float* scratch = (float*)(p->ws + p->o_loss);
         g.mse_target = fl->target; g.mse_target_dtype = fl->tdtype; g.mse_inv_n = (float)(1.0 / (double)fl->mean_elems);
@@ -516,6 +545,8 @@ static int run_gemm(afr_plan* p, hipStream_t s, int flags, const void* A, const 
         return AFR_OK;
     }
     snprintf(tag, sizeof tag, "%s[%dx%dx%d]", afr_gemm_kernel_name(p->cfg.dtype, g), M, N, K);
+    if (coop && !(p->defer && p->pend_tile256 && p->pend.empty() && afr_gemm_groupable(p->cfg.dtype, g)))
+        return fail(AFR_ESTATE, "cooperative split-K product outside a 256x256 grouped launch");
     if (p->defer && afr_gemm_groupable(p->cfg.dtype, g) && p->pend.size() < 4) {
         p->pend.push_back(g); p->pend_tag.push_back(tag); p->pend_flops += fl_; p->pend_bytes += by_;
         return AFR_OK;
@@ -546,7 +577,8 @@ static int flush_gemms(afr_plan* p, hipStream_t s) {
 // dW[N][K] = dy[B][N]^T . a[B][K] and db[N] = sum_b dy, reduced over the batch in ONE GEMM launch (the bias gradient
 // is the column sum of the A tiles the kernel already stages).  Small outputs use split-K partial slabs, summed later
 // by the grouped reduce; large ones (fc_output of the sheet model) write the gradient buffer directly.
-static int run_dw(afr_plan* p, hipStream_t s, const afr_plan::Layer& l, const void* dy, const void* a, int Bn, RTable& rt, int sk_want = 0) {
+static int run_dw(afr_plan* p, hipStream_t s, afr_plan::Layer& l, const void* dy, const void* a, int Bn, RTable& rt, int sk_want = 0,
+                  bool coop = false) {
     const int fl = AFR_GEMM_A_KSTRIDED | AFR_GEMM_B_KSTRIDED;
     const int N = l.N, K = l.K;
     int sk = sk_want > 0 ? sk_want : choose_splitk(N, K, Bn);
@@ -554,6 +586,20 @@ static int run_dw(afr_plan* p, hipStream_t s, const afr_plan::Layer& l, const vo
     if (sk == 1) return run_gemm(p, s, fl, dy, a, p->G + l.w_off, nullptr, nullptr, N, K, Bn, N, K, K, 0, 1, 0, p->G + l.b_off, 0);
     float* sw = (float*)(p->ws + l.o_slab_w);
     float* sb = (float*)(p->ws + l.o_slab_b);
+    if (coop) {
+        // cooperative split-K: the slices meet inside the launch; the product leaves as the finished gradient, or -- during a
+        // fused optimizer step -- as the AdamW update of this weight (its new bf16 copy goes to the write shadow, which the
+        // launch's input-gradient workgroups do not read)
+        CoopArgs ca{sw, (unsigned*)(p->ws + l.o_cnt), ++l.coop_epoch * (unsigned)sk};
+        FusedAdam fa{p->P + l.w_off, p->M + l.w_off, p->V + l.w_off, shadow_wr(p) ? shadow_wr(p) + l.w_off : nullptr,
+                     p->st_decay, p->st_b1, p->st_b2, p->st_eps, p->st_step, p->st_rsqrt_bc2};
+        int rc = run_gemm(p, s, fl, dy, a, p->G + l.w_off, nullptr, nullptr, N, K, Bn, N, K, K, 0, sk, 0, sb, N, nullptr,
+                          p->step_on ? &fa : nullptr, &ca);
+        if (rc) return rc;
+        if (p->step_on) p->adam_done.push_back(l.w_off);
+        afr_rtable_add(rt, p->G + l.b_off, sb, sk, N, N);
+        return AFR_OK;
+    }
     int rc = run_gemm(p, s, fl, dy, a, sw, nullptr, nullptr, N, K, Bn, N, K, K, 0, sk, (long long)N * K, sb, N);
     if (rc) return rc;
     afr_rtable_add(rt, p->G + l.w_off, sw, sk, (long long)N * K, (long long)N * K);
@@ -573,7 +619,7 @@ extern "C" int afr_sync_params(afr_plan* p, void* stream) {
     DevGuard dg(p->device);
     p->wT_valid = false;
     if (p->cfg.dtype != AFR_BF16) return AFR_OK;
-    HIPCHK(afr_launch_f32_to_bf16(p->P, (bf16_t*)(p->ws + p->o_shadow), p->total, (hipStream_t)stream));
+    HIPCHK(afr_launch_f32_to_bf16(p->P, shadow_rd(p), p->total, (hipStream_t)stream));
     return AFR_OK;
 }
 
@@ -751,7 +797,7 @@ static int backward_stage_impl(afr_plan* p, int stage, int64_t* g_off, int64_t* 
     }
     const int nl = (int)p->layers.size();
     const int i = nl - 1 - stage;
-    const auto& l = p->layers[i];
+    auto& l = p->layers[i];
     const void* a = p->ws + p->o_act[i];
     // d(loss)/d(output of layer i): du for the last layer, else the ping-pong buffer the previous stage wrote
     const void* dy = stage == 0 ? du : (const void*)(p->ws + p->o_d[(stage - 1) & 1]);
@@ -817,9 +863,13 @@ static int backward_stage_impl(afr_plan* p, int stage, int64_t* g_off, int64_t* 
         if (dx_tiles >= 232 && l.N >= 256) afr_gemm_pair_plan(B, l.N, l.K, &tile256, &sk_group);
         if (sk_group > l.sk) { sk_group = 0; tile256 = 0; }          // the plan's slab space bounds the split
     }
+    // with 256x256 tiles the weight gradient's split-K slices are summed inside the launch (cooperative split-K): no slabs
+    // for the grouped reduce to re-read; config.reserved bit 5 keeps the slab path (A/B measurements, parity cross-checks)
+    const bool coop = tile256 && (sk_group == 2 || sk_group == 4 || sk_group == 8) && !(c.reserved & 32) &&
+                      (long long)((l.N + 255) / 256) * ((l.K + 255) / 256) * sk_group <= 256;
     p->pend_tile256 = tile256;
     p->defer = sk_group > 0;
-    if ((rc = run_dw(p, s, l, dy, a, B, rt, sk_group))) { p->defer = false; p->pend.clear(); p->pend_tag.clear(); p->pend_flops = p->pend_bytes = 0.0; return rc; }
+    if ((rc = run_dw(p, s, l, dy, a, B, rt, sk_group, coop))) { p->defer = false; p->pend.clear(); p->pend_tag.clear(); p->pend_flops = p->pend_bytes = 0.0; return rc; }
     void* dx = p->ws + p->o_d[stage & 1];
     const int fl = AFR_GEMM_B_KSTRIDED | ob | (i > 0 ? AFR_GEMM_RELU_MASK : 0);
     if ((rc = run_gemm(p, s, fl, dy, weight_ptr(p, l.w_off), dx, nullptr, i > 0 ? a : nullptr, B, l.K, l.N, l.N, l.K, l.K,
@@ -895,7 +945,7 @@ extern "C" int afr_adamw_step(afr_plan* p, float lr, float b1, float b2, float e
     hipStream_t s = (hipStream_t)stream;
     const float bc1 = (float)(1.0 - std::pow((double)b1, (double)t));
     const float bc2 = (float)(1.0 - std::pow((double)b2, (double)t));
-    bf16_t* shadow = p->cfg.dtype == AFR_BF16 ? (bf16_t*)(p->ws + p->o_shadow) : nullptr;
+    bf16_t* shadow = shadow_rd(p);        // nothing reads the weights concurrently: updated in place
     ProfScope ps(p, s, "adamw", 0.0, (double)p->total * (shadow ? 30.0 : 28.0));
     HIPCHK(afr_launch_adamw(p->P, p->G, p->M, p->V, shadow, p->total, lr, b1, b2, eps, wd, bc1, bc2, gscale, s));
     p->wT_valid = false;
@@ -909,7 +959,7 @@ static int reduce_and_step(afr_plan* p, hipStream_t s, RTable& rt, float lr, flo
                            int64_t skip_off = -1) {
     const float bc1 = (float)(1.0 - std::pow((double)b1, (double)t));
     const float bc2 = (float)(1.0 - std::pow((double)b2, (double)t));
-    bf16_t* shadow = p->cfg.dtype == AFR_BF16 ? (bf16_t*)(p->ws + p->o_shadow) : nullptr;
+    bf16_t* shadow = shadow_wr(p);        // every tensor's new bf16 copy goes to the write shadow; the roles swap below
     rt.adam = 1; rt.ad_decay = 1.f - lr * wd; rt.ad_b1 = b1; rt.ad_b2 = b2; rt.ad_eps = eps; rt.ad_step = lr / bc1;
     rt.ad_rsqrt_bc2 = (float)(1.0 / std::sqrt((double)bc2));
     rt.gbase = p->G; rt.P = p->P; rt.M = p->M; rt.V = p->V; rt.shadow = shadow;
@@ -918,6 +968,9 @@ static int reduce_and_step(afr_plan* p, hipStream_t s, RTable& rt, float lr, flo
     if (rc) return rc;
     for (const Tensor& tn : p->params) {
         if (tn.off == skip_off) continue;
+        bool done = false;                 // updated inside its weight-gradient GEMM (cooperative split-K tail)
+        for (int64_t o : p->adam_done) done = done || o == tn.off;
+        if (done) continue;
         // covered by the (disjoint) segments of the grouped reduce -- possibly several per tensor (column ranges)?
         int64_t cov = 0;
         for (int i = 0; i < rt.nseg; ++i) {
@@ -931,6 +984,8 @@ static int reduce_and_step(afr_plan* p, hipStream_t s, RTable& rt, float lr, flo
         HIPCHK(afr_launch_adamw(p->P + tn.off, p->G + tn.off, p->M + tn.off, p->V + tn.off, shadow ? shadow + tn.off : nullptr, n, lr, b1,
                                 b2, eps, wd, bc1, bc2, 1.f, s));
     }
+    if (p->o_shadow2) p->shadow_cur ^= 1;   // every tensor has been rewritten: the write shadow is the current one now
+    p->adam_done.clear();
     return AFR_OK;
 }
 
@@ -948,7 +1003,7 @@ static int sheet_fused_step(afr_plan* p, hipStream_t s, float lr, float b1, floa
     void* du = p->ws + p->o_u;
     void* z = p->ws + p->o_z;
     void* dz = p->ws + p->o_dz;
-    bf16_t* shadow = c.dtype == AFR_BF16 ? (bf16_t*)(p->ws + p->o_shadow) : nullptr;
+    bf16_t* shadow = shadow_rd(p);        // the sheet model keeps ONE shadow: its input-gradient product runs before the update
     const float bc1 = (float)(1.0 - std::pow((double)b1, (double)t));
     const float bc2 = (float)(1.0 - std::pow((double)b2, (double)t));
     int rc;
@@ -1074,8 +1129,15 @@ extern "C" int afr_train_step(afr_plan* p, const int64_t* x, const int64_t* font
         const int n = afr_backward_stages(p);
         RTable rt;
         rt.nseg = 0; rt.nblocks = 0; rt.adam = 0;
+        {   // weight-gradient products with a cooperative split-K tail apply this step's AdamW themselves
+            const float bc1 = (float)(1.0 - std::pow((double)b1, (double)t)), bc2 = (float)(1.0 - std::pow((double)b2, (double)t));
+            p->step_on = true; p->adam_done.clear();
+            p->st_decay = 1.f - lr * wd; p->st_b1 = b1; p->st_b2 = b2; p->st_eps = eps; p->st_step = lr / bc1;
+            p->st_rsqrt_bc2 = (float)(1.0 / std::sqrt((double)bc2));
+        }
         for (int st = 0; st < n; ++st)
-            if ((rc = backward_stage_impl(p, st, nullptr, nullptr, (hipStream_t)stream, &rt))) return rc;
+            if ((rc = backward_stage_impl(p, st, nullptr, nullptr, (hipStream_t)stream, &rt))) { p->step_on = false; return rc; }
+        p->step_on = false;
         p->next_stage = 0;
         p->have_du = false;
         return reduce_and_step(p, (hipStream_t)stream, rt, lr, b1, b2, eps, wd, t);
@@ -1168,6 +1230,48 @@ extern "C" int afr_op_gemm_fix(int flags, const void* A, const void* B, void* C,
     g.fix_ws = (float*)workspace;
     g.fix_cnt = (unsigned*)((char*)workspace + (size_t)(tail * splitk) * AFR_FIX_SLICE_BYTES);
     HIPCHK(afr_launch_gemm_fix(g, (hipStream_t)stream));
+    return AFR_OK;
+}
+static bool pair_plan(int B, int N, int K, int* sk) {
+    int tile256 = 0;
+    *sk = 0;
+    if (B <= 0 || N < 256 || K <= 0) return false;
+    if ((long long)((B + 255) / 256) * ((K + 127) / 128) < 232) return false;          // as backward_stage_impl decides
+    afr_gemm_pair_plan(B, N, K, &tile256, sk);
+    return tile256 && (*sk == 2 || *sk == 4 || *sk == 8) && (long long)((N + 255) / 256) * ((K + 255) / 256) * *sk <= 256;
+}
+extern "C" int afr_op_gemm_pair_plan(int B, int N, int K, int* splitk, size_t* workspace_bytes) {
+    int sk;
+    if (!pair_plan(B, N, K, &sk)) return fail(AFR_EUNSUPPORTED, "%d x %d x %d does not run as a cooperative 256x256 pair", B, N, K);
+    const size_t tiles = (size_t)((N + 255) / 256) * ((K + 255) / 256);
+    if (splitk) *splitk = sk;
+    if (workspace_bytes) *workspace_bytes = tiles * sk * AFR_FIX_SLICE_BYTES + align_up(tiles * sizeof(unsigned), 256);
+    return AFR_OK;
+}
+extern "C" int afr_op_gemm_pair(const void* dy, const void* x, const void* W, const void* aux, float* dW, float* db_part, void* dX,
+                                int B, int N, int K, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!dy || !x || !W || !dW || !db_part || !dX || !workspace) return fail(AFR_EINVAL, "null operand");
+    int sk; size_t need;
+    int rc = afr_op_gemm_pair_plan(B, N, K, &sk, &need);
+    if (rc) return rc;
+    if (N % 8 || K % 8) return fail(AFR_EUNSUPPORTED, "N and K must be multiples of 8");
+    if (workspace_bytes < need || ((uintptr_t)workspace & 255)) return fail(AFR_EINVAL, "workspace too small or misaligned: %zu < %zu", workspace_bytes, need);
+    if ((long long)B * N * 2 >= (1ll << 31) || (long long)B * K * 2 >= (1ll << 31) || (long long)N * K * 2 >= (1ll << 31))
+        return fail(AFR_EUNSUPPORTED, "a bf16 GEMM operand must be smaller than 2 GiB");
+    DevGuard dg(device_of(dW));
+    hipStream_t s = (hipStream_t)stream;
+    const size_t tiles = (size_t)((N + 255) / 256) * ((K + 255) / 256);
+    unsigned* cnt = (unsigned*)((char*)workspace + tiles * sk * AFR_FIX_SLICE_BYTES);
+    HIPCHK(hipMemsetAsync(cnt, 0, align_up(tiles * sizeof(unsigned), 256), s));
+    GemmParams g[2];
+    g[0].A = dy; g[0].B = x; g[0].C = dW; g[0].M = N; g[0].N = K; g[0].K = B; g[0].lda = N; g[0].ldb = K; g[0].ldc = K; g[0].ldaux = 0;
+    g[0].bias = nullptr; g[0].aux = nullptr; g[0].flags = AFR_GEMM_A_KSTRIDED | AFR_GEMM_B_KSTRIDED; g[0].splitk = sk; g[0].slab_stride = 0;
+    g[0].colsum = db_part; g[0].colsum_stride = N;
+    g[0].coop_ws = (float*)workspace; g[0].coop_cnt = cnt; g[0].coop_target = (unsigned)sk; g[0].err = nullptr;
+    g[1].A = dy; g[1].B = W; g[1].C = dX; g[1].M = B; g[1].N = K; g[1].K = N; g[1].lda = N; g[1].ldb = K; g[1].ldc = K; g[1].ldaux = K;
+    g[1].bias = nullptr; g[1].aux = aux; g[1].flags = AFR_GEMM_B_KSTRIDED | AFR_GEMM_OUT_BF16 | (aux ? AFR_GEMM_RELU_MASK : 0);
+    g[1].splitk = 1; g[1].slab_stride = 0;
+    HIPCHK(afr_launch_gemm_group(AFR_BF16, g, 2, 1, s));
     return AFR_OK;
 }
 extern "C" int afr_op_reduce(float* dst, const float* slabs, int nslabs, int64_t stride, int64_t n, float scale, int acc,

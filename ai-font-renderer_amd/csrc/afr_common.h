@@ -118,7 +118,18 @@ struct GemmParams {
     // slice order by the slice block that arrives last (fix_cnt: one zeroed counter per tail tile, re-armed by the kernel).
     // The output then takes the full epilogue (bias / ReLU / mask / bf16), unlike plain split-K's f32 partial slabs.
     int head_tiles = 0; float* fix_ws = nullptr; unsigned* fix_cnt = nullptr;
+    // optional COOPERATIVE split-K (bf16, 256x256 tiles, grouped launches; gemm.hip gemm_bf16_256_body): the `splitk` (2, 4 or
+    // 8) slice workgroups of a tile park their accumulators in coop_ws (256 KiB per slice, write-through), arrive on the
+    // tile's counter and WAIT for each other (every workgroup of the launch is resident: one per CU); then slice z adds rows
+    // [z, z+1) * 128 / splitk ... of every wave's accumulator image over all slices, in slice order, and finishes that strip:
+    // AdamW on p/m/v (ad_p set) or a plain store into C.  No partial slabs leave the kernel and no second kernel re-reads
+    // them.  coop_cnt: one counter per tile, monotonic: a launch waits for coop_target = launches so far * splitk.
+    float* coop_ws = nullptr; unsigned* coop_cnt = nullptr; unsigned coop_target = 0; uint32_t* err = nullptr;
+#ifdef AFR_GEMM_TIMING
+    int dbg_slot = 0;     // kernel-development builds: which 1024-block region of the stamp buffer this launch writes
+#endif
 };
+constexpr uint32_t AFR_ERR_INDEX = 1u, AFR_ERR_COOP_TIMEOUT = 2u;    // bits of the plan's device error word
 // torch.optim.AdamW element update (reference model.py:273,310); shared by adamw_kernel and the fused GEMM epilogue
 __device__ __forceinline__ void adamw_elem(float& p, float& m, float& v, float g, float decay, float b1, float b2,
                                            float eps, float step_size, float rsqrt_bc2) {

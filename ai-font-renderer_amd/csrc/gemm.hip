@@ -336,7 +336,8 @@ __device__ __forceinline__ void nt_st4(float* q, float4 v) {
 // ids, in a buffer of its own (tools/gemm_timeline.py); no output value depends on them.
 #ifdef AFR_GEMM_TIMING
 __device__ unsigned long long* g_gemm_stamps = nullptr;
-#define GSTAMP(i) do { if (stamps && tid == 0) stamps[bid * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define GSLOT ((size_t)p.dbg_slot * 1024 + blockIdx.x)
+#define GSTAMP(i) do { if (stamps && tid == 0) stamps[GSLOT * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define GSTAMP(i) do { } while (0)
 #endif
@@ -500,6 +501,57 @@ __device__ __forceinline__ void wave_epilogue(const GemmParams& p, const f32x4 (
     }
 }
 
+// Finish of one wave's 16 x 64 f32 strip of a weight gradient (cooperative split-K, gemm_bf16_256_body): v[j] holds rows
+// mb + (lane & 15), columns nb0 + 16 j + 4 (lane >> 4) .. +3.  Through the wave's own LDS (4 KiB, XOR-swizzled like
+// wave_epilogue) so that 16 lanes x 16 B cover one 256-byte row segment; then AdamW on p/m/v(/shadow) at the same [m][ldc]
+// position (p.ad_p set) or a plain store of the gradient into C.
+__device__ __forceinline__ void strip_finish(const GemmParams& p, const f32x4 (&v)[4], const int mb, const int nb0, float* Wt, const int lane) {
+    const int ml = lane & 15;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int c = 4 * j + (lane >> 4);
+        *reinterpret_cast<f32x4*>(Wt + ml * 64 + ((c ^ ml) << 2)) = v[j];
+    }
+    const int c4 = lane & 15, nf = nb0 + 4 * c4;
+    const bool okc = nf < p.N;
+    float* Cf = reinterpret_cast<float*>(p.C);
+    const bool adam = p.ad_p != nullptr;
+    float4 qp[4], qm[4], qv[4];
+    if (adam) {
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps) {
+            const int m = mb + ps * 4 + (lane >> 4);
+            if (m < p.M && okc) {
+                const size_t wi = (size_t)m * p.ldc + nf;
+                qp[ps] = ADLD(p.ad_p + wi); qm[ps] = ADLD(p.ad_m + wi); qv[ps] = ADLD(p.ad_v + wi);
+            }
+        }
+    }
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) {
+        const int rl = ps * 4 + (lane >> 4);
+        const f32x4 g = *reinterpret_cast<const f32x4*>(Wt + rl * 64 + ((c4 ^ rl) << 2));
+        const int m = mb + rl;
+        if (m >= p.M || !okc) continue;
+        const size_t wi = (size_t)m * p.ldc + nf;
+        if (adam) {
+            float pp[4] = {qp[ps].x, qp[ps].y, qp[ps].z, qp[ps].w}, mm[4] = {qm[ps].x, qm[ps].y, qm[ps].z, qm[ps].w};
+            float vv[4] = {qv[ps].x, qv[ps].y, qv[ps].z, qv[ps].w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) adamw_elem(pp[r], mm[r], vv[r], g[r], p.ad_decay, p.ad_b1, p.ad_b2, p.ad_eps, p.ad_step, p.ad_rsqrt_bc2);
+            ADST(p.ad_p + wi, make_float4(pp[0], pp[1], pp[2], pp[3]));
+            ADST(p.ad_m + wi, make_float4(mm[0], mm[1], mm[2], mm[3]));
+            ADST(p.ad_v + wi, make_float4(vv[0], vv[1], vv[2], vv[3]));
+            if (p.ad_shadow) {
+                bf16x4 o = {(bf16_t)pp[0], (bf16_t)pp[1], (bf16_t)pp[2], (bf16_t)pp[3]};
+                __builtin_nontemporal_store(o, reinterpret_cast<bf16x4*>(p.ad_shadow + wi));
+            }
+        } else {
+            nt_st4(Cf + wi, make_float4(g[0], g[1], g[2], g[3]));
+        }
+    }
+}
+
 template <int WM> struct RingGeom {
     static constexpr int ASUB = WM / 2, STAGES = (WM == 4) ? 3 : 2, STAGE_BYTES = (ASUB + 1) * SUB, LDS_BYTES = STAGES * STAGE_BYTES;
 };
@@ -523,7 +575,7 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmParams& p, const int bi
         unsigned xcc, hwid;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-        stamps[bid * 8 + 4] = xcc; stamps[bid * 8 + 5] = hwid;
+        stamps[GSLOT * 8 + 4] = xcc; stamps[GSLOT * 8 + 5] = hwid;
     }
 #endif
     int tm, tn, z;
@@ -884,6 +936,15 @@ __device__ __forceinline__ void gemm_bf16_256_body(const GemmParams& p, const in
         tile_of_block(p, BM, BNN, bid, nblk, tm, tn, z);
         if (z >= p.splitk) return;
     }
+#ifdef AFR_GEMM_TIMING
+    unsigned long long* stamps = g_gemm_stamps;
+    GSTAMP(0);
+    if (stamps && tid == 0) {
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        stamps[GSLOT * 8 + 4] = xcc; stamps[GSLOT * 8 + 5] = (unsigned)(p.coop_ws ? 1 : 0);
+    }
+#endif
     const int m0 = tm * BM, n0 = tn * BNN;
     const int klen = ((p.K + ksplit - 1) / ksplit + BK - 1) / BK * BK;
     const int kbeg = z * klen;
@@ -974,6 +1035,7 @@ __device__ __forceinline__ void gemm_bf16_256_body(const GemmParams& p, const in
     if (nt > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");     // tile 0 has landed; tile 1 is retired by the wait of phase 3
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    GSTAMP(1);
     if (wr == 1) __builtin_amdgcn_s_barrier();          // waves 4..7 run one barrier behind from here on
 
     bf16x8 fa[2][4], fb[2][4];                          // [k-step][fragment]: A half (64 rows), all 64 B columns
@@ -1028,6 +1090,7 @@ __device__ __forceinline__ void gemm_bf16_256_body(const GemmParams& p, const in
     if (wr == 0) __builtin_amdgcn_s_barrier();          // the leading group meets the trailing group's last barrier
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    GSTAMP(2);
 
     if (ALAY == 1 && do_cs) {
         float* red = reinterpret_cast<float*>(smem);           // [16 row groups][BM]
@@ -1042,6 +1105,82 @@ __device__ __forceinline__ void gemm_bf16_256_body(const GemmParams& p, const in
             p.colsum[(size_t)z * p.colsum_stride + m0 + tid] = a;
         }
         __syncthreads();
+    }
+    if (p.coop_ws) {
+        // Cooperative split-K (GemmParams::coop_ws): the S = splitk slice workgroups of this tile exchange their partial
+        // sums inside the launch.  Hand-off form (MI355X_MICROARCH.md, visibility table, first row): every payload byte is
+        // stored write-through (sc1) and drained by its wave, the workgroup meets at a barrier, ONE lane adds to the tile's
+        // counter; wave 0 polls that counter with sc1 loads (bounded: a missing partner sets AFR_ERR_COOP_TIMEOUT in the
+        // error word instead of hanging the GPU), the other waves pass the next barrier behind it, and every load of the
+        // parked bytes is an sc1 load -- no fence on either side.  A grouped launch has at most one workgroup per CU (160
+        // KiB of LDS) and these come first in its grid, so all S partners are resident whenever >= their number of CUs is
+        // free; the input-gradient workgroups behind them never wait for anybody.
+        // Parking layout (a register image, every access a whole 1 KiB wave access): slice z of tile T holds, per wave w and
+        // accumulator (i, j), 64 lanes x 16 B at (((T*S + z)*8 + w)*32 + 4 i + j) KiB.  Slice z then owns accumulator rows
+        // i in [z, z+1) * 8/S of every wave and adds them over the slices IN SLICE ORDER: the sums do not depend on arrival.
+        const int S = p.splitk, per = 8 / S;
+        const int T = tm * ((p.N + BNN - 1) / BNN) + tn;
+        const __amdgpu_buffer_rsrc_t rws = __builtin_amdgcn_make_buffer_rsrc(p.coop_ws, 0, 0x7FFFFFFF, 0x00020000);
+        typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+        const unsigned tile_b = (unsigned)T * (unsigned)S * (8u * 32u * 1024u);          // < 2 GiB: checked by the launcher
+        {
+            const unsigned mine = tile_b + ((unsigned)z * 8u + (unsigned)wave) * (32u * 1024u) + (unsigned)lane * 16u;
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[i][j]), rws, mine + (unsigned)(i * 4 + j) * 1024u, 0, 16);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // every storing wave drains its own stores
+        __syncthreads();
+        GSTAMP(6);
+        if (wave == 0) {
+            if (lane == 0) (void)__hip_atomic_fetch_add(p.coop_cnt + T, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            unsigned spins = 0;
+            while ((int)(__hip_atomic_load(p.coop_cnt + T, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - p.coop_target) < 0) {
+                __builtin_amdgcn_s_sleep(8);
+                if (++spins > (1u << 22)) {                              // seconds: a partner never ran
+                    if (lane == 0 && p.err) atomicOr(p.err, AFR_ERR_COOP_TIMEOUT);
+                    break;
+                }
+            }
+        }
+        __syncthreads();
+        GSTAMP(7);
+        float* Wt = reinterpret_cast<float*>(smem) + wave * 4096;
+        for (int ii = 0; ii < per; ++ii) {
+            const int i = z * per + ii;
+            // all 8 x 4 loads of the strip in flight at once; slices >= S read past the descriptor (zeros): one code path for
+            // every S, and the sum starts from +0 exactly as the slab reduction's does (bitwise equal results)
+            const unsigned src = tile_b + (unsigned)wave * (32u * 1024u) + (unsigned)(i * 4) * 1024u + (unsigned)lane * 16u;
+            f32x4 v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {                    // two rounds of 4 slices: 16 loads (64 VGPRs) in flight per lane
+                f32x4 q[4][4];
+#pragma unroll
+                for (int zq = 0; zq < 4; ++zq) {
+                    const int zz = 4 * h + zq;
+                    // (the range check looks at the VGPR offset only, so that is where the out-of-range marker goes)
+                    const unsigned vo = zz < S ? src + (unsigned)zz * (8u * 32u * 1024u) : 0x80000000u;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        q[zq][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rws, vo, (unsigned)j * 1024u, 16));
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int zq = 0; zq < 4; ++zq) v[j] += q[zq][j];
+            }
+            strip_finish(p, v, m0 + wr * 128 + 16 * i, n0 + wc * 64, Wt, lane);
+        }
+#ifdef AFR_GEMM_TIMING
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        GSTAMP(3);
+#endif
+        return;
     }
     if (tail_idx >= 0) {
         // park this K-slice, take a ticket; only the tile's last arrival goes on (see the mapping above)
@@ -1088,6 +1227,11 @@ __device__ __forceinline__ void gemm_bf16_256_body(const GemmParams& p, const in
         wave_epilogue<ALAY, BLAY, 4>(p, part, m0 + wr * 128 + h * 64, n0 + wc * 64, z, Wt, lane, lsum);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the wave's own LDS reads of pass 0 are done before pass 1 overwrites Wt
     }
+#ifdef AFR_GEMM_TIMING
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    GSTAMP(3);
+#endif
 }
 
 template <int ALAY, int BLAY, int WM, int ABL = 0>
@@ -1289,9 +1433,15 @@ static int g_gemm_variant = getenv("AFR_GEMM_VARIANT") ? atoi(getenv("AFR_GEMM_V
 extern "C" void afr_dbg_set_gemm_variant(int v) { g_gemm_variant = v; }
 #endif
 #ifdef AFR_GEMM_TIMING
+static int g_dbg_slot = 0;
 extern "C" int afr_dbg_gemm_stamps(void* devbuf) {
+    g_dbg_slot = 0;
     return (int)hipMemcpyToSymbol(HIP_SYMBOL(bf16k::g_gemm_stamps), &devbuf, sizeof(void*));
 }
+extern "C" void afr_dbg_gemm_slot_reset(void) { g_dbg_slot = 0; }
+#define DBG_SLOT(q) (q).dbg_slot = g_dbg_slot++ & 63
+#else
+#define DBG_SLOT(q) do { } while (0)
 #endif
 // bf16: the 256x128 / 8-wave kernel when its grid fills most of the 256 CUs, else 128x128 / 4 waves
 static bool bf16_use_wide(const GemmParams& p) {
@@ -1314,7 +1464,7 @@ const char* afr_gemm_kernel_name(int dtype, const GemmParams& p) {
 }
 // true when the product would run on the 256x128 ring kernel by itself (what a grouped launch is built from)
 bool afr_gemm_groupable(int dtype, const GemmParams& p) {
-    return dtype == AFR_BF16 && p.M > 0 && p.N > 0 && !p.mse_target && !p.ad_p && p.K / p.splitk >= 256;
+    return dtype == AFR_BF16 && p.M > 0 && p.N > 0 && !p.mse_target && (!p.ad_p || p.coop_ws) && p.K / p.splitk >= 256;
 }
 // How a layer's gradient pair (dX: B x K_in over N_out; dW: N_out x K_in over the batch) is launched: with 256x256 tiles
 // when those fill most of the chip in ONE round (dW split so that its blocks run as many K-tiles as dX's), else with
@@ -1374,9 +1524,19 @@ hipError_t afr_launch_gemm_fix(const GemmParams& p, hipStream_t s) {
 }
 hipError_t afr_launch_gemm_group(int dtype, const GemmParams* ps, int n, int tile256, hipStream_t s) {
     if (n <= 0) return hipSuccess;
-    bool ok = n <= 4;
+    bool ok = n <= 4, coop = false;
     for (int i = 0; i < n && ok; ++i) ok = afr_gemm_groupable(dtype, ps[i]);
-    if (!ok || n == 1) {
+    for (int i = 0; i < n; ++i) {
+        if (!ps[i].coop_ws) continue;
+        // cooperative split-K exists in the 256x256 body only, one workgroup per CU, partners resident together
+        const long long tiles = (long long)((ps[i].M + 255) / 256) * ((ps[i].N + 255) / 256);
+        const int S = ps[i].splitk;
+        // (listed first: the dispatcher hands out workgroups in grid order, so the waiting ones all become resident)
+        if (i != 0 || !ok || !tile256 || !ps[i].coop_cnt || (S != 2 && S != 4 && S != 8) || tiles * S > 256 ||
+            tiles * S * (long long)AFR_FIX_SLICE_BYTES >= (1ll << 31)) return hipErrorInvalidValue;
+        coop = true;
+    }
+    if (!ok || (n == 1 && !coop)) {
         for (int i = 0; i < n; ++i) { hipError_t e = afr_launch_gemm(dtype, ps[i], s); if (e != hipSuccess) return e; }
         return hipSuccess;
     }
@@ -1390,11 +1550,20 @@ hipError_t afr_launch_gemm_group(int dtype, const GemmParams* ps, int n, int til
         total += (nb + 7) & ~7;        // each product's range starts on a multiple of 8: blocks b, b+8, ... keep sharing an XCD
     }
     g.blk0[n] = total;
+#ifdef AFR_GEMM_TIMING
+    { const int slot = g_dbg_slot++ & 63; for (int i = 0; i < n; ++i) g.p[i].dbg_slot = slot; }
+#endif
     if (tile256) hipLaunchKernelGGL(bf16k::gemm_bf16_group256, dim3(total), dim3(512), 0, s, g);
     else hipLaunchKernelGGL(bf16k::gemm_bf16_group, dim3(total), dim3(512), 0, s, g);
     return hipGetLastError();
 }
-hipError_t afr_launch_gemm(int dtype, const GemmParams& p, hipStream_t s) {
+hipError_t afr_launch_gemm(int dtype, const GemmParams& p_in, hipStream_t s) {
+#ifdef AFR_GEMM_TIMING
+    GemmParams p = p_in;
+    DBG_SLOT(p);
+#else
+    const GemmParams& p = p_in;
+#endif
     const int a = (p.flags & AFR_GEMM_A_KSTRIDED) ? 1 : 0, b = (p.flags & AFR_GEMM_B_KSTRIDED) ? 1 : 0;
     if (p.M <= 0 || p.N <= 0) return hipSuccess;
     if (dtype == AFR_BF16) {

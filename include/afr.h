@@ -64,7 +64,10 @@ typedef struct afr_config {
                             bit 3: OPT IN to in-launch split-K (afr_op_gemm_fix) for the sheet model's fc_output products
                             that have no fused loss / optimizer tail (today: the input gradient)
                             bit 4: the glyph nets' folded first layer backward through the weight-gradient GEMM + post-pass
-                            instead of the fused kernel (A/B measurements, parity cross-checks)                          */
+                            instead of the fused kernel (A/B measurements, parity cross-checks)
+                            bit 5: weight gradients of grouped 256x256 launches as split-K partial slabs summed by the grouped
+                            reduce, instead of the cooperative split-K whose slices meet inside the launch (A/B measurements,
+                            parity cross-checks: the two give bitwise equal results)                                    */
 } afr_config;
 
 typedef struct afr_plan afr_plan;
@@ -143,7 +146,8 @@ int afr_train_step(afr_plan* plan, const int64_t* x, const int64_t* font, const 
                    float weight_decay, int64_t t, void* stream);
 
 /* Set / read the device-side error word (bit 0: an embedding index outside [0,vocab), the
- * condition on which the reference raises IndexError; model.py:136,167).  Reading synchronises and clears. */
+ * condition on which the reference raises IndexError; model.py:136,167; bit 1: a cooperative split-K
+ * workgroup gave up waiting for its partners -- the step's results are invalid).  Reading synchronises and clears. */
 int afr_error_flags(afr_plan* plan, void* stream, uint32_t* flags_out);
 
 /* Name and average duration (ms, hipEvent-timed on the launch stream) of the plan's dominant
@@ -190,10 +194,21 @@ size_t afr_op_gemm_fix_workspace_bytes(int M, int N, int head_tiles, int splitk)
 int afr_op_gemm_fix(int flags, const void* A, const void* B, void* C, const float* bias, const void* aux,
                     int M, int N, int K, int lda, int ldb, int ldc, int ldaux, int head_tiles, int splitk,
                     void* workspace, size_t workspace_bytes, void* stream);
+/* A Linear layer's two gradient products exactly as afr_train_step issues them in bf16 mode when the pair fills the chip
+ * with 256x256 tiles -- ONE grouped launch (reference: what autograd derives from nn.Linear, model.py:148,152,309):
+ *     dW[N][K]      = dy^T . x          f32; the split-K slices are summed INSIDE the launch (cooperative split-K)
+ *     db_part[s][N] = column sums of dy over K-slice s, s < splitk (the caller adds the rows)
+ *     dX[B][K]      = (dy . W) * (aux > 0)   bf16 (aux NULL: no mask)
+ * dy [B][N], x [B][K], W [N][K], aux [B][K]: bf16, row-major, dense.  afr_op_gemm_pair_plan returns AFR_OK with the split
+ * and the workspace size, or AFR_EUNSUPPORTED when the shape does not take this form (the step then uses separate
+ * launches).  workspace: 256-byte aligned; its contents need not be preserved between calls. */
+int afr_op_gemm_pair_plan(int B, int N, int K, int* splitk, size_t* workspace_bytes);
+int afr_op_gemm_pair(const void* dy, const void* x, const void* W, const void* aux, float* dW, float* db_part, void* dX,
+                     int B, int N, int K, void* workspace, size_t workspace_bytes, void* stream);
 int afr_op_reduce(float* dst, const float* slabs, int nslabs, int64_t slab_stride, int64_t n,
                   float scale, int accumulate, void* stream);
 /* Several slab reductions in ONE launch (what a backward pass uses for all its split-K / per-block partial gradients):
- * dst[i][0..n[i]) = sum_s slabs[i][s*stride[i] + ...], s < nslabs[i], fixed order.  At most 24 segments: more is an
+ * dst[i][0..n[i]) = sum_s slabs[i][s*stride[i] + ...], s < nslabs[i], fixed order.  At most 32 segments: more is an
  * error (AFR_EINVAL), never a silent drop.  n[i] must be a multiple of 4. */
 int afr_op_reduce_group(int nseg, float* const* dst, const float* const* slabs, const int* nslabs,
                         const int64_t* stride, const int64_t* n, void* stream);

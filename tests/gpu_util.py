@@ -94,3 +94,26 @@ def gemm_fix(A_log, B_log, head_tiles, splitk, a_kstrided=False, b_kstrided=Fals
     tail = tiles - min(head_tiles, tiles)
     counters = ws[tail * splitk * 256 * 256 * 4:].view(torch.int32).cpu()
     return outs, counters
+
+
+def gemm_pair(dy, x, W, aux=None, repeats=1):
+    """A layer's gradient pair through afr_op_gemm_pair (ONE grouped 256x256 launch, cooperative split-K).  dy [B][N],
+    x [B][K], W [N][K], aux [B][K] float tensors (rounded to bf16 here).  Returns the list of (dW f32 [N][K], db f32 [N],
+    dX f32 [B][K]) CPU results of `repeats` launches on one workspace, and the split."""
+    lib = _lib.lib()
+    B, N = dy.shape
+    K = x.shape[1]
+    sk, need = C.c_int(), C.c_size_t()
+    _lib.check(lib.afr_op_gemm_pair_plan(B, N, K, C.byref(sk), C.byref(need)))
+    dyd, xd, Wd = dev(dy, torch.bfloat16), dev(x, torch.bfloat16), dev(W, torch.bfloat16)
+    auxd = dev(aux, torch.bfloat16) if aux is not None else None
+    ws = torch.full((need.value,), 0x5A, dtype=torch.uint8, device="cuda")     # dirty on purpose: the op owns its state
+    outs = []
+    for _ in range(repeats):
+        dW = torch.full((N, K), float("nan"), dtype=torch.float32, device="cuda")
+        dbp = torch.full((sk.value, N), float("nan"), dtype=torch.float32, device="cuda")
+        dX = torch.full((B, K), float("nan"), dtype=torch.bfloat16, device="cuda")
+        _lib.check(lib.afr_op_gemm_pair(ptr(dyd), ptr(xd), ptr(Wd), ptr(auxd), ptr(dW), ptr(dbp), ptr(dX), B, N, K, ptr(ws), need.value, stream()))
+        torch.cuda.synchronize()
+        outs.append((dW.cpu(), dbp.sum(0).cpu(), dX.float().cpu()))
+    return outs, sk.value

@@ -200,6 +200,69 @@ def test_in_launch_splitk_gemm(M, N, K, head, sk, ak, bk):
     assert float((outs[0].double() - ref * (aux > 0)).abs().max()) < 1e-2 * scale
 
 
+@pytest.mark.parametrize("B,N,K,sk_want", [
+    (8192, 1024, 1024, 8),        # C3's hidden layers: 128 input-gradient tiles + 16 weight-gradient tiles x 8 slices
+    (8192, 2048, 1024, 4),        # 32 x 4 slices
+    (8192, 4096, 1024, 2),        # 64 x 2 slices
+    (8000, 1000, 1016, 8),        # ragged in every extent; the last K-slice is short
+])
+def test_grouped_gradient_pair_vs_fp64(B, N, K, sk_want):
+    """afr_op_gemm_pair = the launch that takes 45 % of a C3 step (gemm_bf16_group256: a layer's dW with cooperative
+    split-K + dX with the ReLU mask, one grid): dW and db against fp64 at f32-accumulation accuracy, dX at bf16 output
+    accuracy, bitwise equal from launch to launch, and dX bitwise equal to the stand-alone afr_op_gemm product."""
+    from .gpu_util import gemm, gemm_pair
+    dy, x = _b16(_rand(161, (B, N), 0.05)), _b16(_rand(162, (B, K)))
+    W, aux = _b16(_rand(163, (N, K), 0.2)), _b16(_rand(164, (B, K)))
+    outs, sk = gemm_pair(dy, x, W, aux, repeats=3)
+    assert sk == sk_want
+    dW, db, dX = outs[0]
+    ref_w = dy.double().t() @ x.double()
+    assert float((dW.double() - ref_w).abs().max()) < 1e-5 * float(ref_w.abs().max())
+    ref_b = dy.double().sum(0)
+    assert float((db.double() - ref_b).abs().max()) < 1e-5 * float(ref_b.abs().max())
+    ref_x = (dy.double() @ W.double()) * (aux > 0)
+    assert float((dX.double() - ref_x).abs().max()) < 1e-2 * float(ref_x.abs().max())
+    for o in outs[1:]:
+        assert torch.equal(o[0], dW) and torch.equal(o[1], db) and torch.equal(o[2], dX)
+    solo = gemm("bf16", dy, W.t().contiguous(), b_kstrided=True, aux=aux, out_bf16=True)       # B(n,k) = W[k][n]
+    assert float((solo - dX).abs().max()) <= 2e-2 * float(ref_x.abs().max())                    # at most one bf16 ulp apart
+    dXn = gemm_pair(dy, x, W, None)[0][0][2]
+    assert float((dXn.double() - dy.double() @ W.double()).abs().max()) < 1e-2 * float(ref_x.abs().max())
+
+
+def test_c3_cooperative_splitk_equals_slabs_and_separate_launches():
+    """C3 at its batch, bf16: the step's grouped backward launches with the cooperative split-K tail (default), with
+    split-K slabs + grouped reduce (config.reserved bit 5) and as one launch per product (bit 1).  Gradients: default ==
+    slabs bit for bit (same slices, same order); against separate launches to f32 accumulation-order rounding.  Then three
+    optimizer steps: AdamW inside the weight-gradient GEMM == AdamW inside the slab reduction, bit for bit."""
+    from ai_font_renderer_amd.config import WORKLOADS
+    cfg, B = WORKLOADS["c3"]["cfg"], 8192
+    x, font, tu8 = glyph_inputs(cfg, B)
+    xt, ft, tt = torch.from_numpy(x), torch.from_numpy(font), torch.from_numpy(tu8)
+    engs = {fl: _engine(cfg, dtype="bf16", max_batch=B, flags=fl) for fl in (0, 32, 2)}
+    for e in engs.values():
+        e.train_step(xt, tt, font=ft, do_step=False)
+        e.read_loss()
+    for k in engs[0].grads:
+        assert torch.equal(engs[0].grads[k], engs[32].grads[k]), k
+        ref = engs[2].grads[k]
+        assert float((engs[0].grads[k] - ref).abs().max()) <= 1e-5 * float(ref.abs().max()), k
+    for _ in range(3):
+        for fl in (0, 32):
+            engs[fl].train_step(xt, tt, font=ft)
+    assert abs(engs[0].read_loss() - engs[32].read_loss()) == 0.0
+    assert torch.equal(engs[0].flat_params, engs[32].flat_params)
+    assert torch.equal(engs[0].exp_avg, engs[32].exp_avg) and torch.equal(engs[0].exp_avg_sq, engs[32].exp_avg_sq)
+    for e in engs.values():
+        assert e.error_flags() == 0
+    # the bf16 copies the next forward reads are those of the updated masters
+    for fl in (0, 32):
+        y = engs[fl].forward(xt[:512], ft[:512])
+        e2 = _engine(cfg, dtype="bf16", max_batch=512)
+        e2.load_params({k: v.cpu() for k, v in engs[fl].state_dict().items()})
+        assert torch.equal(y, e2.forward(xt[:512], ft[:512])), fl
+
+
 @pytest.mark.parametrize("cfgkw,B,flags", [
     (dict(hidden=(1024, 1024), out_h=32, out_w=32, n_fonts=2), 8192, 0),     # C3: 128 row blocks x 2 column ranges
     (dict(hidden=(1024, 512), out_h=16, out_w=16, n_fonts=2), 1000, 0),      # ragged last block, 4 column ranges
