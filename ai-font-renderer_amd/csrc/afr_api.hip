@@ -84,6 +84,9 @@ struct afr_plan {
     bool wT_valid = false;         // bf16: the transposed operand copies W1T / W2T match the current parameters
     size_t o_w1t = 0, o_w2t = 0, o_slab1 = 0;
     bool l1f = false; size_t o_l1f = 0;   // glyph, bf16: folded first layer's backward in one kernel (slabs [blocks][dW1|db1|dTab])
+    // glyph, bf16 training steps: the first layer's output as a COMBINATION table (elementwise.hip glyph_combo_kernel): h1 / h0
+    // are not materialised per glyph; the products that consume them gather table rows through cidx while staging
+    bool combo_ok = false, combo_on = false; size_t o_h1c = 0, o_h0c = 0, o_cidx = 0; int h1c_ld = 0;
     size_t o_fix = 0, o_fixcnt = 0; bool have_fix = false;   // in-launch split-K: slice parking area + per-tile arrival counters
     // bf16 glyph nets: TWO weight shadows.  A fused optimizer step writes every tensor's new bf16 copy into the one that is
     // not being read (a layer's weight-gradient workgroups update the weights while the same launch's input-gradient
@@ -275,6 +278,14 @@ extern "C" int afr_plan_create(const afr_config* c, afr_plan** out) {
             }
         }
         p->o_slab_e = carve(eb * (size_t)(c->vocab + c->n_fonts) * E * sizeof(float));
+        {
+            const size_t ncombo = (size_t)c->vocab * (c->n_fonts > 0 ? c->n_fonts : 1);
+            if (c->dtype == AFR_BF16 && p->l1f && c->n_hidden >= 2 && ncombo <= 1024 && !(c->reserved & (64 | 16))) {
+                p->combo_ok = true;
+                p->h1c_ld = c->hidden[0] + (getenv("AFR_H1C_PAD") ? atoi(getenv("AFR_H1C_PAD")) : 0);      // kernel A/B measurements
+                p->o_h1c = carve(ncombo * p->h1c_ld * 2); p->o_h0c = carve(ncombo * E * 2); p->o_cidx = carve(B * sizeof(int));
+            }
+        }
         if (c->n_hidden == 1 && afr_glyph1_eligible(E, c->hidden[0], Pix, c->vocab, c->n_fonts) &&
             afr_glyph1_lds_bytes(c->dtype, E, c->hidden[0], Pix, c->vocab + c->n_fonts) <= 160 * 1024) {
             p->fused1 = true;
@@ -489,6 +500,7 @@ extern "C" int afr_profile_dump(afr_plan* p, char* buf, int cap) {
 struct FusedLoss { const void* target; int tdtype; int64_t mean_elems; float* loss_accum; };
 struct FusedAdam { float *p, *m, *v; bf16_t* shadow; float decay, b1, b2, eps, step_size, rsqrt_bc2; };
 struct CoopArgs { float* ws; unsigned* cnt; unsigned target; };
+struct RowMaps { const int* a; const int* b; const int* aux; };     // GemmParams::a_rowmap / b_rowmap / aux_rowmap
 // the bf16 weight shadow the GEMMs read / the one a fused optimizer step writes (the same buffer unless the plan has two)
 static inline bf16_t* shadow_rd(const afr_plan* p) {
     if (p->cfg.dtype != AFR_BF16) return nullptr;
@@ -506,7 +518,7 @@ static inline const void* weight_ptr(const afr_plan* p, int64_t off) {
 static int run_gemm(afr_plan* p, hipStream_t s, int flags, const void* A, const void* B, void* C, const float* bias,
                     const void* aux, int M, int N, int K, int lda, int ldb, int ldc, int ldaux, int splitk,
                     long long slab_stride, float* colsum = nullptr, long long colsum_stride = 0, const FusedLoss* fl = nullptr,
-                    const FusedAdam* fa = nullptr, const CoopArgs* coop = nullptr) {
+                    const FusedAdam* fa = nullptr, const CoopArgs* coop = nullptr, const RowMaps* rm = nullptr) {
     if (p->cfg.dtype == AFR_BF16) {
         const bool ak = flags & AFR_GEMM_A_KSTRIDED, bk = flags & AFR_GEMM_B_KSTRIDED;
         const long long ea = (long long)(ak ? K : M) * lda * 2, ebb = (long long)(bk ? K : N) * ldb * 2;
@@ -518,6 +530,7 @@ static int run_gemm(afr_plan* p, hipStream_t s, int flags, const void* A, const 
         g.ad_decay = fa->decay; g.ad_b1 = fa->b1; g.ad_b2 = fa->b2; g.ad_eps = fa->eps; g.ad_step = fa->step_size; g.ad_rsqrt_bc2 = fa->rsqrt_bc2;
     }
     g.colsum = colsum; g.colsum_stride = colsum_stride;
+    if (rm) { g.a_rowmap = rm->a; g.b_rowmap = rm->b; g.aux_rowmap = rm->aux; }
     if (coop) { g.coop_ws = coop->ws; g.coop_cnt = coop->cnt; g.coop_target = coop->target; g.err = (uint32_t*)(p->ws + p->o_err); }
     if (fl) {
         float* scratch = (float*)(p->ws + p->o_loss);
@@ -547,6 +560,8 @@ static int run_gemm(afr_plan* p, hipStream_t s, int flags, const void* A, const 
     snprintf(tag, sizeof tag, "%s[%dx%dx%d]", afr_gemm_kernel_name(p->cfg.dtype, g), M, N, K);
     if (coop && !(p->defer && p->pend_tile256 && p->pend.empty() && afr_gemm_groupable(p->cfg.dtype, g)))
         return fail(AFR_ESTATE, "cooperative split-K product outside a 256x256 grouped launch");
+    if (rm && rm->b && !(p->defer && p->pend_tile256 && afr_gemm_groupable(p->cfg.dtype, g)))
+        return fail(AFR_ESTATE, "gathered k-strided operand outside a 256x256 grouped launch");
     if (p->defer && afr_gemm_groupable(p->cfg.dtype, g) && p->pend.size() < 4) {
         p->pend.push_back(g); p->pend_tag.push_back(tag); p->pend_flops += fl_; p->pend_bytes += by_;
         return AFR_OK;
@@ -578,7 +593,10 @@ static int flush_gemms(afr_plan* p, hipStream_t s) {
 // is the column sum of the A tiles the kernel already stages).  Small outputs use split-K partial slabs, summed later
 // by the grouped reduce; large ones (fc_output of the sheet model) write the gradient buffer directly.
 static int run_dw(afr_plan* p, hipStream_t s, afr_plan::Layer& l, const void* dy, const void* a, int Bn, RTable& rt, int sk_want = 0,
-                  bool coop = false) {
+                  bool coop = false, const int* a_rows = nullptr, int a_ld = 0) {
+    const RowMaps rmv{nullptr, a_rows, nullptr};
+    const RowMaps* rm = a_rows ? &rmv : nullptr;          // the layer's input rows are gathered from a table (k-strided B operand)
+    if (rm && !coop) return fail(AFR_ESTATE, "gathered weight-gradient operand needs the cooperative 256x256 launch");
     const int fl = AFR_GEMM_A_KSTRIDED | AFR_GEMM_B_KSTRIDED;
     const int N = l.N, K = l.K;
     int sk = sk_want > 0 ? sk_want : choose_splitk(N, K, Bn);
@@ -593,8 +611,8 @@ static int run_dw(afr_plan* p, hipStream_t s, afr_plan::Layer& l, const void* dy
         CoopArgs ca{sw, (unsigned*)(p->ws + l.o_cnt), ++l.coop_epoch * (unsigned)sk};
         FusedAdam fa{p->P + l.w_off, p->M + l.w_off, p->V + l.w_off, shadow_wr(p) ? shadow_wr(p) + l.w_off : nullptr,
                      p->st_decay, p->st_b1, p->st_b2, p->st_eps, p->st_step, p->st_rsqrt_bc2};
-        int rc = run_gemm(p, s, fl, dy, a, p->G + l.w_off, nullptr, nullptr, N, K, Bn, N, K, K, 0, sk, 0, sb, N, nullptr,
-                          p->step_on ? &fa : nullptr, &ca);
+        int rc = run_gemm(p, s, fl, dy, a, p->G + l.w_off, nullptr, nullptr, N, K, Bn, N, a_rows ? a_ld : K, K, 0, sk, 0, sb, N, nullptr,
+                          p->step_on ? &fa : nullptr, &ca, rm);
         if (rc) return rc;
         if (p->step_on) p->adam_done.push_back(l.w_off);
         afr_rtable_add(rt, p->G + l.b_off, sb, sk, N, N);
@@ -647,6 +665,31 @@ static SheetParams sheet_params(const afr_plan* p) {
     return sp;
 }
 
+// How a glyph layer's gradient pair (dW + dX) leaves at batch B: as ONE grouped launch (sk_group > 0) on 256x256 tiles
+// (tile256) with the weight gradient's slices meeting inside the launch (coop), or as separate launches (all zero).
+struct PairPlan { int sk_group = 0, tile256 = 0; bool coop = false; };
+static PairPlan pair_plan_for(const afr_plan* p, const afr_plan::Layer& l, int B) {
+    PairPlan pp;
+    const afr_config& c = p->cfg;
+    if (c.dtype != AFR_BF16 || (c.reserved & 2)) return pp;
+    const long long dx_tiles = (long long)((B + 255) / 256) * ((l.K + 127) / 128);
+    if (dx_tiles >= 232 && l.N >= 256) afr_gemm_pair_plan(B, l.N, l.K, &pp.tile256, &pp.sk_group);
+    if (pp.sk_group > l.sk) { pp.sk_group = 0; pp.tile256 = 0; }          // the plan's slab space bounds the split
+    // with 256x256 tiles the weight gradient's split-K slices are summed inside the launch (cooperative split-K): no slabs
+    // for the grouped reduce to re-read; config.reserved bit 5 keeps the slab path (A/B measurements, parity cross-checks)
+    pp.coop = pp.tile256 && (pp.sk_group == 2 || pp.sk_group == 4 || pp.sk_group == 8) && !(c.reserved & 32) &&
+              (long long)((l.N + 255) / 256) * ((l.K + 255) / 256) * pp.sk_group <= 256;
+    return pp;
+}
+// A training forward at batch B runs the first layer as a combination table when every consumer of h1 / h0 can gather: the
+// second layer's forward on the 256x128 ring kernel, its gradient pair as a cooperative 256x256 launch, the fused first-layer
+// backward.
+static bool combo_for(const afr_plan* p, int B) {
+    if (!p->combo_ok || p->layers.size() < 3) return false;
+    const auto& l2 = p->layers[1];
+    return afr_gemm_wide_ok(B, l2.N, l2.K) && pair_plan_for(p, l2, B).coop;
+}
+
 // ------------------------------------------------------------------------------------- forward
 static int forward_impl(afr_plan* p, const int64_t* x, const int64_t* font, int B, int L, float* y, int training,
                         uint64_t step, void* stream, const FusedLoss* fl) {
@@ -681,7 +724,18 @@ static int forward_impl(afr_plan* p, const int64_t* x, const int64_t* font, int 
         const int nl = (int)p->layers.size();
         const float* femb = c.n_fonts > 0 ? p->P + p->font_off : nullptr;
         int first = 0;
-        if (p->k0) {
+        const bool combo = fl != nullptr && p->k0 && combo_for(p, B);
+        const RowMaps rma{(const int*)(p->ws + p->o_cidx), nullptr, nullptr};
+        if (combo) {
+            // training step: the first layer as a combination table; the second layer gathers its input rows from it
+            const auto& l = p->layers[0];
+            ProfScope ps(p, s, "glyph_l1_combo", 0.0, (double)c.vocab * (c.n_fonts > 0 ? c.n_fonts : 1) * l.N * 2.0);
+            HIPCHK(afr_launch_glyph_combo(p->P + p->emb_off, femb, p->P + l.w_off, p->P + l.b_off, x, font, B, c.embed_dim, l.N, c.vocab,
+                                          c.n_fonts, (float*)(p->ws + p->o_table), p->ws + p->o_h1c, p->h1c_ld, p->ws + p->o_h0c,
+                                          (int*)(p->ws + p->o_cidx), err, s, p->ws + p->o_w1t));
+            h = p->ws + p->o_h1c;
+            first = 1;
+        } else if (p->k0) {
             // hidden layer 1 as a table gather (see glyph_table_kernel); also leaves h0 for the backward dW GEMM
             const auto& l = p->layers[0];
             ProfScope ps(p, s, "glyph_l1_fwd", 0.0, (double)B * l.N * p->act_bytes);
@@ -699,7 +753,8 @@ static int forward_impl(afr_plan* p, const int64_t* x, const int64_t* font, int 
             const bool last = (i == nl - 1);
             void* outp = last ? u : (void*)(p->ws + p->o_act[i + 1]);
             int rc = run_gemm(p, s, AFR_GEMM_BIAS | (last ? 0 : AFR_GEMM_RELU) | ob, h, weight_ptr(p, l.w_off), outp,
-                              p->P + l.b_off, nullptr, B, l.N, l.K, l.K, l.K, l.N, 0, 1, 0, nullptr, 0, last ? fl : nullptr);
+                              p->P + l.b_off, nullptr, B, l.N, l.K, (combo && i == 1) ? p->h1c_ld : l.K, l.K, l.N, 0, 1, 0, nullptr, 0,
+                              last ? fl : nullptr, nullptr, nullptr, (combo && i == 1) ? &rma : nullptr);
             if (rc) return rc;
             h = outp;
         }
@@ -711,6 +766,7 @@ static int forward_impl(afr_plan* p, const int64_t* x, const int64_t* font, int 
     }
     p->last_x = x; p->last_font = font; p->last_B = B; p->last_training = training; p->last_step = step;
     p->next_stage = 0;
+    p->combo_on = c.kind == AFR_KIND_GLYPH && fl != nullptr && p->k0 && combo_for(p, B);
     p->have_du = fl != nullptr;      // with the loss fused into the last layer's epilogue the buffer already holds du
     return AFR_OK;
 }
@@ -813,7 +869,9 @@ static int backward_stage_impl(afr_plan* p, int stage, int64_t* g_off, int64_t* 
             const long long st = afr_glyph_l1_bwd_fused_slab_floats(B, l.N, c.vocab, c.n_fonts);
             {
                 ProfScope ps(p, s, "glyph_l1_bwd_fused", 2.0 * B * l.N * (2.0 * E + 1.0), (double)B * l.N * 2.0 + (double)nb * st * 4.0);
-                HIPCHK(afr_launch_glyph_l1_bwd_fused(dy, l.N, a, K0, p->ws + p->o_w1t, p->last_x, p->last_font, B, l.N, c.vocab, c.n_fonts, sl, s));
+                if (p->combo_on) HIPCHK(afr_launch_glyph_l1_bwd_fused(dy, l.N, p->ws + p->o_h0c, E, p->ws + p->o_w1t, p->last_x, p->last_font, B, l.N,
+                                                                      c.vocab, c.n_fonts, sl, s, (const int*)(p->ws + p->o_cidx)));
+                else HIPCHK(afr_launch_glyph_l1_bwd_fused(dy, l.N, a, K0, p->ws + p->o_w1t, p->last_x, p->last_font, B, l.N, c.vocab, c.n_fonts, sl, s));
             }
             // block = (row block, column range): range cs's slabs are blocks cs, cs + CS, ...; every block has a dTab partial
             for (int cs = 0; cs < CS; ++cs) {
@@ -857,23 +915,24 @@ static int backward_stage_impl(afr_plan* p, int stage, int64_t* g_off, int64_t* 
     // chip with 256x128 tiles they go out as ONE grouped launch, the weight gradient first and split so that one of its
     // blocks runs twice the K-tiles of an input-gradient block (half the slabs of the stand-alone choice; a CU draws
     // either one long block or two short ones).
-    int sk_group = 0, tile256 = 0;
-    if (c.dtype == AFR_BF16 && !(c.reserved & 2)) {
-        const long long dx_tiles = (long long)((B + 255) / 256) * ((l.K + 127) / 128);
-        if (dx_tiles >= 232 && l.N >= 256) afr_gemm_pair_plan(B, l.N, l.K, &tile256, &sk_group);
-        if (sk_group > l.sk) { sk_group = 0; tile256 = 0; }          // the plan's slab space bounds the split
+    const PairPlan pp = pair_plan_for(p, l, B);
+    const int sk_group = pp.sk_group, tile256 = pp.tile256;
+    const bool coop = pp.coop;
+    // the layer whose input is the first layer's output: after a combination-table forward its rows are gathered from H1c
+    const bool gath = p->combo_on && i == 1;
+    const int* cidx = gath ? (const int*)(p->ws + p->o_cidx) : nullptr;
+    if (gath) {
+        if (!coop) return fail(AFR_ESTATE, "combination-table forward without a cooperative gradient pair (batch changed?)");
+        a = p->ws + p->o_h1c;
     }
-    // with 256x256 tiles the weight gradient's split-K slices are summed inside the launch (cooperative split-K): no slabs
-    // for the grouped reduce to re-read; config.reserved bit 5 keeps the slab path (A/B measurements, parity cross-checks)
-    const bool coop = tile256 && (sk_group == 2 || sk_group == 4 || sk_group == 8) && !(c.reserved & 32) &&
-                      (long long)((l.N + 255) / 256) * ((l.K + 255) / 256) * sk_group <= 256;
     p->pend_tile256 = tile256;
     p->defer = sk_group > 0;
-    if ((rc = run_dw(p, s, l, dy, a, B, rt, sk_group, coop))) { p->defer = false; p->pend.clear(); p->pend_tag.clear(); p->pend_flops = p->pend_bytes = 0.0; return rc; }
+    if ((rc = run_dw(p, s, l, dy, a, B, rt, sk_group, coop, cidx, p->h1c_ld))) { p->defer = false; p->pend.clear(); p->pend_tag.clear(); p->pend_flops = p->pend_bytes = 0.0; return rc; }
     void* dx = p->ws + p->o_d[stage & 1];
     const int fl = AFR_GEMM_B_KSTRIDED | ob | (i > 0 ? AFR_GEMM_RELU_MASK : 0);
+    const RowMaps rmx{nullptr, nullptr, cidx};
     if ((rc = run_gemm(p, s, fl, dy, weight_ptr(p, l.w_off), dx, nullptr, i > 0 ? a : nullptr, B, l.K, l.N, l.N, l.K, l.K,
-                       l.K, 1, 0))) { p->defer = false; p->pend.clear(); p->pend_tag.clear(); p->pend_flops = p->pend_bytes = 0.0; return rc; }
+                       gath ? p->h1c_ld : l.K, 1, 0, nullptr, 0, nullptr, nullptr, nullptr, gath ? &rmx : nullptr))) { p->defer = false; p->pend.clear(); p->pend_tag.clear(); p->pend_flops = p->pend_bytes = 0.0; return rc; }
     if ((rc = flush_gemms(p, s))) return rc;
     const int64_t end = l.b_off + (l.N + 63) / 64 * 64;
     if (i > 0) {

@@ -125,6 +125,11 @@ struct GemmParams {
     // AdamW on p/m/v (ad_p set) or a plain store into C.  No partial slabs leave the kernel and no second kernel re-reads
     // them.  coop_cnt: one counter per tile, monotonic: a launch waits for coop_target = launches so far * splitk.
     float* coop_ws = nullptr; unsigned* coop_cnt = nullptr; unsigned coop_target = 0; uint32_t* err = nullptr;
+    // optional row gather (bf16): memory row r of the operand (a row m of a k-contiguous A, a row k of a k-strided B, a row m
+    // of aux) is row rowmap[r] of the table the operand pointer names.  The glyph nets' first-layer output as a combination
+    // table (elementwise.hip glyph_combo_kernel).  Supported: A k-contiguous on the 256x128 ring kernel, B k-strided on the
+    // 256x256 kernel, aux with a bf16 output; the launchers refuse anything else.
+    const int* a_rowmap = nullptr; const int* b_rowmap = nullptr; const int* aux_rowmap = nullptr;
 #ifdef AFR_GEMM_TIMING
     int dbg_slot = 0;     // kernel-development builds: which 1024-block region of the stamp buffer this launch writes
 #endif
@@ -150,6 +155,7 @@ constexpr size_t AFR_FIX_SLICE_BYTES = 256 * 256 * 4, AFR_FIX_MAX_SLICES = 256, 
 bool afr_gemm_fix_plan(int M, int N, int K, int* head_tiles, int* splitk);
 hipError_t afr_launch_gemm_fix(const GemmParams& p, hipStream_t s);
 const char* afr_gemm_kernel_name(int dtype, const GemmParams& p);
+bool afr_gemm_wide_ok(int M, int N, int K);      // a bf16 product of this shape (no split, no fused optimizer) runs on the 256x128 ring kernel
 
 hipError_t afr_launch_reduce(float* dst, const float* slabs, int nslabs, long long slab_stride, long long n,
                              float scale, int accumulate, hipStream_t s);
@@ -194,6 +200,10 @@ int afr_embed_bwd_blocks(int B);
 hipError_t afr_launch_glyph_l1_fwd(int act_dtype, const float* emb, const float* font_emb, const float* W1, const float* b1,
                                    const int64_t* x, const int64_t* font, int B, int E, int N1, int vocab, int n_fonts,
                                    float* table, void* h0, void* h1, uint32_t* err_flag, hipStream_t s, void* w1t = nullptr);
+hipError_t afr_launch_glyph_combo(const float* emb, const float* font_emb, const float* W1, const float* b1, const int64_t* x,
+                                  const int64_t* font, int B, int E, int N1, int vocab, int n_fonts, float* table, void* h1c,
+                                  int ld1 /* row stride of h1c, elements */, void* h0c, int* cidx, uint32_t* err_flag, hipStream_t s,
+                                  void* w1t);
 int afr_glyph_k0(int E, int vocab, int n_fonts);
 int afr_glyph_l1_bwd_blocks(int N1);
 // the same backward in one kernel (throughput mode, gemm.hip: glyph_l1_bwd_fused_kernel); W1T = bf16 [E][N1] from the forward
@@ -202,7 +212,8 @@ int afr_glyph_l1_bwd_fused_split(int B, int N1);                                
 int afr_glyph_l1_bwd_fused_blocks(int B, int N1);
 long long afr_glyph_l1_bwd_fused_slab_floats(int B, int N1, int vocab, int n_fonts);   // [dW1 nc*E | db1 nc | dTab rows*E], nc = N1 / split
 hipError_t afr_launch_glyph_l1_bwd_fused(const void* d1, int ldd, const void* h0, int ldh, const void* W1T, const int64_t* x,
-                                         const int64_t* font, int B, int N1, int vocab, int n_fonts, float* slabs, hipStream_t s);
+                                         const int64_t* font, int B, int N1, int vocab, int n_fonts, float* slabs, hipStream_t s,
+                                         const int* h0_rowmap = nullptr);
 hipError_t afr_launch_glyph_l1_bwd(const float* slabs, int nslabs, long long slab_stride, const float* W1, int N1, int E,
                                    int vocab, int n_fonts, float* dw1, float* dtab_part, hipStream_t s);
 hipError_t afr_launch_glyph_embed_bwd(int act_dtype, const void* d, const int64_t* x, const int64_t* font, int B,

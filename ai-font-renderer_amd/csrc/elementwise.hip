@@ -505,6 +505,73 @@ hipError_t afr_launch_glyph_l1_fwd(int act_dtype, const float* emb, const float*
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------- first layer as a COMBINATION table (training steps, bf16)
+// A glyph is one of vocab x max(n_fonts, 1) (character, font) combinations, so the first layer's output has at most that many
+// distinct rows.  A training step therefore does not materialise h1 [B][N1] (16 MB at C3, written once and read three times:
+// by the next layer's forward, by its weight gradient and by its ReLU mask) but only
+//     H1c[c][n] = bf16(relu(T[x][n] + b1[n] + T[vocab + f][n]))      c = x * max(n_fonts, 1) + f   (the gather kernel's arithmetic)
+//     H0c[c][k] = bf16(Emb[x][k] + Font[f][k])
+//     cidx[b]   = c of glyph b
+// (0.5 MB + 16 KB + 32 KB, L2-resident); the GEMM kernels that consume h1 / h0 gather their operand rows through cidx while
+// staging (GemmParams::a_rowmap / b_rowmap / aux_rowmap; LDS-DMA takes a per-lane source address, so a gathered row costs
+// what a dense one does).  Same values bit for bit as the gather kernel's h1 / h0, same FLOPs in every product.
+__global__ __launch_bounds__(256) void glyph_combo_kernel(const float* __restrict__ table, const float* __restrict__ b1,
+                                                          const float* __restrict__ emb, const float* __restrict__ femb,
+                                                          const int64_t* __restrict__ x, const int64_t* __restrict__ font,
+                                                          int B, int E, int N1, int vocab, int n_fonts, int tab_blocks,
+                                                          bf16_t* __restrict__ h1c, int ld1, bf16_t* __restrict__ h0c, int* __restrict__ cidx,
+                                                          uint32_t* err_flag) {
+    const int nf = max(n_fonts, 1);
+    if ((int)blockIdx.x >= tab_blocks) {                  // the batch's combination indices (with the index check of the gather)
+        const int b = ((int)blockIdx.x - tab_blocks) * 256 + threadIdx.x;
+        if (b >= B) return;
+        long long xi = x[b], fi = (n_fonts > 0 && font) ? font[b] : 0;
+        if (xi < 0 || xi >= vocab) { atomicOr(err_flag, 1u); xi = min(max(xi, 0ll), (long long)vocab - 1); }
+        if (n_fonts > 0 && (fi < 0 || fi >= n_fonts)) { atomicOr(err_flag, 1u); fi = min(max(fi, 0ll), (long long)n_fonts - 1); }
+        cidx[b] = (int)(xi * nf + fi);
+        return;
+    }
+    const int c = blockIdx.x, xi = c / nf, fi = c - xi * nf;
+    const float* trow_c = table + (size_t)xi * N1;
+    const float* trow_f = table + (size_t)(vocab + fi) * N1;
+    for (int n = 8 * threadIdx.x; n < N1; n += 8 * 256) {
+        float v[8];
+        const float4 a0 = *reinterpret_cast<const float4*>(trow_c + n), a1 = *reinterpret_cast<const float4*>(trow_c + n + 4);
+        const float4 g0 = *reinterpret_cast<const float4*>(b1 + n), g1 = *reinterpret_cast<const float4*>(b1 + n + 4);
+        v[0] = a0.x + g0.x; v[1] = a0.y + g0.y; v[2] = a0.z + g0.z; v[3] = a0.w + g0.w;
+        v[4] = a1.x + g1.x; v[5] = a1.y + g1.y; v[6] = a1.z + g1.z; v[7] = a1.w + g1.w;
+        if (n_fonts > 0) {
+            const float4 f0 = *reinterpret_cast<const float4*>(trow_f + n), f1 = *reinterpret_cast<const float4*>(trow_f + n + 4);
+            v[0] += f0.x; v[1] += f0.y; v[2] += f0.z; v[3] += f0.w; v[4] += f1.x; v[5] += f1.y; v[6] += f1.z; v[7] += f1.w;
+        }
+        bf16x8 w;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) w[r] = (bf16_t)fmaxf(v[r], 0.f);
+        *reinterpret_cast<bf16x8*>(h1c + (size_t)c * ld1 + n) = w;
+    }
+    if ((int)threadIdx.x < E) {
+        float v = emb[(size_t)xi * E + threadIdx.x];
+        if (n_fonts > 0) v += femb[(size_t)fi * E + threadIdx.x];
+        h0c[(size_t)c * E + threadIdx.x] = (bf16_t)v;
+    }
+}
+// table (as glyph_l1_fwd) + combination rows + combination indices; h1c [vocab * max(n_fonts,1)][N1], h0c [..][E], cidx [B]
+hipError_t afr_launch_glyph_combo(const float* emb, const float* font_emb, const float* W1, const float* b1, const int64_t* x,
+                                  const int64_t* font, int B, int E, int N1, int vocab, int n_fonts, float* table, void* h1c,
+                                  int ld1, void* h0c, int* cidx, uint32_t* err_flag, hipStream_t s, void* w1t) {
+    if (B <= 0) return hipSuccess;
+    if ((N1 & 7) || (E & 7) || E > 256) return hipErrorInvalidValue;
+    const int rows = vocab + n_fonts;
+    const size_t tlds = (size_t)(256 * (E + 1) + GT_ROWS * E) * sizeof(float);
+    if (tlds > 48 * 1024) return hipErrorInvalidValue;                 // the combination path is planned for E <= 32 .. 40
+    hipLaunchKernelGGL(glyph_table_kernel, dim3((rows + GT_ROWS - 1) / GT_ROWS, (N1 + 255) / 256), dim3(256), tlds, s, emb, font_emb,
+                       W1, vocab, rows, E, N1, table, (bf16_t*)w1t);
+    const int tab_blocks = vocab * (n_fonts > 0 ? n_fonts : 1);
+    hipLaunchKernelGGL(glyph_combo_kernel, dim3(tab_blocks + (B + 255) / 256), dim3(256), 0, s, table, b1, emb, font_emb, x, font, B, E,
+                       N1, vocab, n_fonts, tab_blocks, (bf16_t*)h1c, ld1, (bf16_t*)h0c, cidx, err_flag);
+    return hipGetLastError();
+}
+
 // columns of h0': E + (vocab + n_fonts) rounded up to 8
 int afr_glyph_k0(int E, int vocab, int n_fonts) { return E + (vocab + n_fonts + 7) / 8 * 8; }
 

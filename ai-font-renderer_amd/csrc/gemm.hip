@@ -278,9 +278,10 @@ __device__ __forceinline__ unsigned piece_voff(int ld, int X, int x0, int k0, in
     if (gx >= X || gk >= kend) off = 0x80000000u;
     return off;
 }
+// rowmap (optional): the operand's memory row (x for LAY 0, k for LAY 1) is row rowmap[row] of the table behind rsrc
 template <int LAY>
 __device__ __forceinline__ void stage_inst(i32x4 rsrc, unsigned lds_sub, int ld, int X, int x0, int k0,
-                                           int kend, int inst, int lane) {
+                                           int kend, int inst, int lane, const int* rowmap = nullptr) {
     int gx, gk;
     if (LAY == 0) {
         const int r = inst * 8 + (lane >> 3);
@@ -291,8 +292,11 @@ __device__ __forceinline__ void stage_inst(i32x4 rsrc, unsigned lds_sub, int ld,
         const int c = (lane & 15) ^ (fswz(kr) << 1);
         gk = k0 + kr; gx = x0 + 8 * c;
     }
-    unsigned off = (LAY == 0) ? (unsigned)(((size_t)gx * ld + gk) * 2) : (unsigned)(((size_t)gk * ld + gx) * 2);
-    if (gx >= X || gk >= kend) off = 0x80000000u;
+    const bool oob = gx >= X || gk >= kend;
+    int rx = gx, rk = gk;
+    if (rowmap && !oob) { if (LAY == 0) rx = rowmap[gx]; else rk = rowmap[gk]; }
+    unsigned off = (LAY == 0) ? (unsigned)(((size_t)rx * ld + gk) * 2) : (unsigned)(((size_t)rk * ld + gx) * 2);
+    if (oob) off = 0x80000000u;
     dma16(rsrc, lds_sub + inst * 1024, off);
 }
 // fragment for 16 x-rows starting at xb (multiple of 16, within the sub-tile), k-step ks (32 k each): lane holds
@@ -385,11 +389,17 @@ __device__ __forceinline__ void wave_epilogue(const GemmParams& p, const f32x4 (
     bf16x8 auxv[8];
     uint2 tu8[8];
     if (relu_mask || (mse && p.mse_target_dtype == AFR_TARGET_U8)) {
+        int am[8];                                   // aux rows (gathered through aux_rowmap when the mask operand is a table)
+#pragma unroll
+        for (int ps = 0; ps < 8; ++ps) {
+            const int m = mb + ps * 8 + (lane >> 3);
+            am[ps] = (relu_mask && p.aux_rowmap && m < p.M) ? p.aux_rowmap[m] : m;
+        }
 #pragma unroll
         for (int ps = 0; ps < 8; ++ps) {
             const int m = mb + ps * 8 + (lane >> 3);
             if (m < p.M && ncol) {
-                if (relu_mask) auxv[ps] = *reinterpret_cast<const bf16x8*>(aux + (size_t)m * p.ldaux + n);
+                if (relu_mask) auxv[ps] = *reinterpret_cast<const bf16x8*>(aux + (size_t)am[ps] * p.ldaux + n);
                 if (mse) tu8[ps] = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint8_t*>(p.mse_target) + (size_t)m * p.N + n);
             }
         }
@@ -502,10 +512,31 @@ __device__ __forceinline__ void wave_epilogue(const GemmParams& p, const f32x4 (
 }
 
 // Finish of one wave's 16 x 64 f32 strip of a weight gradient (cooperative split-K, gemm_bf16_256_body): v[j] holds rows
-// mb + (lane & 15), columns nb0 + 16 j + 4 (lane >> 4) .. +3.  Through the wave's own LDS (4 KiB, XOR-swizzled like
-// wave_epilogue) so that 16 lanes x 16 B cover one 256-byte row segment; then AdamW on p/m/v(/shadow) at the same [m][ldc]
-// position (p.ad_p set) or a plain store of the gradient into C.
-__device__ __forceinline__ void strip_finish(const GemmParams& p, const f32x4 (&v)[4], const int mb, const int nb0, float* Wt, const int lane) {
+// mb + (lane & 15), columns nb0 + 16 j + 4 (lane >> 4) .. +3.  Through the wave's own LDS (Wt: 16 KiB; the first 4 KiB take
+// the strip, XOR-swizzled like wave_epilogue) so that 16 lanes x 16 B cover one 256-byte row segment; then AdamW on
+// p/m/v(/shadow) at the same [m][ldc] position (p.ad_p set) or a plain store of the gradient into C.
+// strip_prefetch brings the strip's p/m/v into the other 12 KiB of Wt by LDS-DMA (no VGPRs: the kernel has none to spare
+// around its K loop) in the layout of the finish -- pass ps covers rows mb + 4 ps + (lane >> 4), columns nb0 + 4 (lane & 15)
+// ..+3; lane l's 16 bytes of tensor t land at Wt + 4 KiB + (3 ps + t) KiB + 16 l.  The cooperative tail issues it before it
+// parks its accumulators, so the optimizer state arrives under the park / wait / slice-load chain; the caller's
+// s_waitcnt vmcnt(0) (the park's drain) retires it before the finish reads it.
+__device__ __forceinline__ void strip_prefetch(const GemmParams& p, const int mb, const int nb0, const int lane, float* Wt) {
+    const unsigned lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)(reinterpret_cast<char*>(Wt) + 4096);
+    const i32x4 rp = make_rsrc(p.ad_p), rm = make_rsrc(p.ad_m), rv = make_rsrc(p.ad_v);
+    const int nf = nb0 + 4 * (lane & 15);
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) {
+        const int m = mb + ps * 4 + (lane >> 4);
+        // (32-bit byte offsets: the launcher admits the fused optimizer here only for tensors below 2 GiB)
+        const unsigned off = (m < p.M && nf < p.N) ? (unsigned)(((size_t)m * p.ldc + nf) * 4) : 0x80000000u;
+        dma16(rp, lds + (3 * ps + 0) * 1024, off);
+        dma16(rm, lds + (3 * ps + 1) * 1024, off);
+        dma16(rv, lds + (3 * ps + 2) * 1024, off);
+    }
+}
+// pre: the strip's p/m/v were prefetched into Wt (strip_prefetch); else they are loaded here
+__device__ __forceinline__ void strip_finish(const GemmParams& p, const f32x4 (&v)[4], const int mb, const int nb0, float* Wt, const int lane,
+                                             const bool pre) {
     const int ml = lane & 15;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -516,17 +547,7 @@ __device__ __forceinline__ void strip_finish(const GemmParams& p, const f32x4 (&
     const bool okc = nf < p.N;
     float* Cf = reinterpret_cast<float*>(p.C);
     const bool adam = p.ad_p != nullptr;
-    float4 qp[4], qm[4], qv[4];
-    if (adam) {
-#pragma unroll
-        for (int ps = 0; ps < 4; ++ps) {
-            const int m = mb + ps * 4 + (lane >> 4);
-            if (m < p.M && okc) {
-                const size_t wi = (size_t)m * p.ldc + nf;
-                qp[ps] = ADLD(p.ad_p + wi); qm[ps] = ADLD(p.ad_m + wi); qv[ps] = ADLD(p.ad_v + wi);
-            }
-        }
-    }
+    const float4* pmv = reinterpret_cast<const float4*>(Wt + 1024) + lane;       // + (3 ps + t) * 64
 #pragma unroll
     for (int ps = 0; ps < 4; ++ps) {
         const int rl = ps * 4 + (lane >> 4);
@@ -535,8 +556,10 @@ __device__ __forceinline__ void strip_finish(const GemmParams& p, const f32x4 (&
         if (m >= p.M || !okc) continue;
         const size_t wi = (size_t)m * p.ldc + nf;
         if (adam) {
-            float pp[4] = {qp[ps].x, qp[ps].y, qp[ps].z, qp[ps].w}, mm[4] = {qm[ps].x, qm[ps].y, qm[ps].z, qm[ps].w};
-            float vv[4] = {qv[ps].x, qv[ps].y, qv[ps].z, qv[ps].w};
+            float4 qp, qm, qv;
+            if (pre) { qp = pmv[(3 * ps + 0) * 64]; qm = pmv[(3 * ps + 1) * 64]; qv = pmv[(3 * ps + 2) * 64]; }
+            else { qp = ADLD(p.ad_p + wi); qm = ADLD(p.ad_m + wi); qv = ADLD(p.ad_v + wi); }
+            float pp[4] = {qp.x, qp.y, qp.z, qp.w}, mm[4] = {qm.x, qm.y, qm.z, qm.w}, vv[4] = {qv.x, qv.y, qv.z, qv.w};
 #pragma unroll
             for (int r = 0; r < 4; ++r) adamw_elem(pp[r], mm[r], vv[r], g[r], p.ad_decay, p.ad_b1, p.ad_b2, p.ad_eps, p.ad_step, p.ad_rsqrt_bc2);
             ADST(p.ad_p + wi, make_float4(pp[0], pp[1], pp[2], pp[3]));
@@ -559,8 +582,10 @@ template <int WM> struct RingGeom {
 // passes its own blockIdx / gridDim; a grouped launch (gemm_bf16_group) a sub-range of its grid.
 // ABL (kernel-development builds only, -DAFR_GEMM_LAB): ablation bits for the ring loop -- 1: no DMA inside the loop,
 // 2: no fragment reads inside the loop, 4: no MFMAs.  Results are wrong by construction; only the time is read.
-template <int ALAY, int BLAY, int WM, int ABL = 0>
+// GA: the k-contiguous A operand's rows are gathered through p.a_rowmap (ALAY == 0, WM == 4 only)
+template <int ALAY, int BLAY, int WM, int ABL = 0, int GA = 0>
 __device__ __forceinline__ void gemm_bf16_body(const GemmParams& p, const int bid, const int nblk, char* smem) {
+    static_assert(!GA || (ALAY == 0 && WM == 4), "row gather: k-contiguous A on the 256x128 ring kernel");
     constexpr int BM = 64 * WM, NW = 2 * WM, ASUB = WM / 2;
     constexpr int STAGES = RingGeom<WM>::STAGES;
     constexpr int STAGE_BYTES = RingGeom<WM>::STAGE_BYTES;
@@ -633,6 +658,18 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmParams& p, const int bi
             }
         }
     }
+    // gathered A rows: a piece's 8 rows are no longer 8 * lda apart, so every piece of the wave gets its own lane offset
+    // (looked up ONCE: a block's rows are the same for every K-tile) and only the K-tile remains in the SGPR offset
+    unsigned fvAq[GA ? A_PER_WAVE : 1];
+    if (GA) {
+#pragma unroll
+        for (int q = 0; q < A_PER_WAVE; ++q) {
+            const int g = wave * A_PER_WAVE + q, r8 = lane >> 3;
+            const int row = m0 + (g >> 4) * 128 + (g & 15) * 8 + r8;
+            const int trow = row < p.M ? p.a_rowmap[row] : 0;
+            fvAq[q] = (unsigned)(((size_t)trow * p.lda + kbeg + 8 * ((lane & 7) ^ (r8 & 7))) * 2);
+        }
+    }
     const unsigned fpA = (ALAY == 0 ? 8u : 4u) * p.lda * 2, fpB = (BLAY == 0 ? 8u : 4u) * p.ldb * 2;     // bytes per piece step
     const unsigned ftA = ALAY == 0 ? 128u : 64u * p.lda * 2, ftB = BLAY == 0 ? 128u : 64u * p.ldb * 2;   // bytes per K-tile
     auto dma_s = [&](i32x4 rsrc, unsigned lds_addr, unsigned voff, unsigned soff) {
@@ -645,7 +682,8 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmParams& p, const int bi
         const unsigned S = lds0 + slot * STAGE_BYTES;
         if (q < A_PER_WAVE) {
             const int g = wave * A_PER_WAVE + q;
-            dma_s(rA, S + (g >> 4) * SUB + (g & 15) * 1024, fvA[A_PER_WAVE >= 4 ? (q >> 1) : 0], (unsigned)t * ftA + (unsigned)q * fpA);
+            if (GA) dma_s(rA, S + (g >> 4) * SUB + (g & 15) * 1024, fvAq[q], (unsigned)t * ftA);
+            else dma_s(rA, S + (g >> 4) * SUB + (g & 15) * 1024, fvA[A_PER_WAVE >= 4 ? (q >> 1) : 0], (unsigned)t * ftA + (unsigned)q * fpA);
         } else {
             const int i = q - A_PER_WAVE;
             dma_s(rB, S + ASUB * SUB + (wave * B_PER_WAVE + i) * 1024, fvB[B_PER_WAVE >= 4 ? (i >> 1) : 0], (unsigned)t * ftB + (unsigned)i * fpB);
@@ -663,7 +701,7 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmParams& p, const int bi
         for (int i = 0; i < A_PER_WAVE; ++i) {
             const int g = wave * A_PER_WAVE + i;
             const int sub = g >> 4;
-            stage_inst<ALAY>(rA, S + sub * SUB, p.lda, p.M, m0 + sub * 128, k0, kend, g & 15, lane);
+            stage_inst<ALAY>(rA, S + sub * SUB, p.lda, p.M, m0 + sub * 128, k0, kend, g & 15, lane, GA ? p.a_rowmap : nullptr);
         }
 #pragma unroll
         for (int i = 0; i < B_PER_WAVE; ++i)
@@ -704,7 +742,7 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmParams& p, const int bi
         if (q < A_PER_WAVE) {
             const int g = wave * A_PER_WAVE + q;
             const int sub = g >> 4;
-            stage_inst<ALAY>(rA, S + sub * SUB, p.lda, p.M, m0 + sub * 128, k0, kend, g & 15, lane);
+            stage_inst<ALAY>(rA, S + sub * SUB, p.lda, p.M, m0 + sub * 128, k0, kend, g & 15, lane, GA ? p.a_rowmap : nullptr);
         } else {
             stage_inst<BLAY>(rB, S + ASUB * SUB, p.ldb, p.N, n0, k0, kend, wave * B_PER_WAVE + (q - A_PER_WAVE), lane);
         }
@@ -904,8 +942,10 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmParams& p, const int bi
 //     -- at least two phases before it is overwritten, so also the trailing group's reads are retired.  ONE counted wait
 //     per K-tile, in phase 3 ahead of its first barrier: the four newest sub-tiles (tile t+2) stay in flight, tile t+1 has
 //     landed; its first read is two barriers later (the trailing group's wait sits one barrier after the leading one's).
-template <int ALAY, int BLAY, int ABL = 0>
+// GB: the k-strided B operand's rows (its k index: batch rows of a weight-gradient product) are gathered through p.b_rowmap
+template <int ALAY, int BLAY, int ABL = 0, int GB = 0>
 __device__ __forceinline__ void gemm_bf16_256_body(const GemmParams& p, const int bid, const int nblk, char* smem) {
+    static_assert(!GB || BLAY == 1, "row gather: k-strided B on the 256x256 kernel");
     constexpr int BM = 256, BNN = 256;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -973,8 +1013,42 @@ __device__ __forceinline__ void gemm_bf16_256_body(const GemmParams& p, const in
         if (ALAY == 0) { const int r = lane >> 3; voffA = (unsigned)(((size_t)(m0 + r) * p.lda + kbeg + 8 * ((lane & 7) ^ (r & 7))) * 2); }
         else { const int kr = lane >> 4, c = (lane & 15) ^ ((((kr & 3) | (w1 << 2))) << 1); voffA = (unsigned)(((size_t)(kbeg + kr) * p.lda + m0 + 8 * c) * 2); }
         if (BLAY == 0) { const int r = lane >> 3; voffB = (unsigned)(((size_t)(n0 + r) * p.ldb + kbeg + 8 * ((lane & 7) ^ (r & 7))) * 2); }
-        else { const int kr = lane >> 4, c = (lane & 15) ^ ((((kr & 3) | (w1 << 2))) << 1); voffB = (unsigned)(((size_t)(kbeg + kr) * p.ldb + n0 + 8 * c) * 2); }
+        else { const int kr = lane >> 4, c = (lane & 15) ^ ((((kr & 3) | (w1 << 2))) << 1); voffB = (unsigned)(((size_t)(GB ? 0 : kbeg + kr) * p.ldb + n0 + 8 * c) * 2); }
     }
+    // Gathered B rows (GB): k-row kbeg + 64 t + 4 (2 wave + i) + (lane >> 4) of piece i is row b_rowmap[..] of the table.  The
+    // wave's two pieces cover 8 consecutive k-rows, so their table rows are ONE scalar load of 8 indices per K-tile (issued in
+    // phase 0 for tile t+2, behind that phase's own lgkmcnt(0) by phase 1, where each lane picks its row: 2 VGPRs per tile).
+    typedef __attribute__((ext_vector_type(8))) int i32x8;
+    unsigned gvb[2] = {0u, 0u};
+    // (the base pointer is formed ONCE: re-reading p.b_rowmap from the kernel arguments inside the loop puts a scalar-load
+    // wait, i.e. a wait for the phase's LDS reads too, in front of the phase's DMA issue)
+    const __attribute__((address_space(4))) int* bm_base = nullptr;
+    if (GB) {
+        const unsigned long long a0 = (unsigned long long)(p.b_rowmap + kbeg + wave * 8);
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a0), hi = __builtin_amdgcn_readfirstlane((unsigned)(a0 >> 32));
+        bm_base = (const __attribute__((address_space(4))) int*)(((unsigned long long)hi << 32) | lo);
+    }
+    auto bmap_load = [&](int t) -> i32x8 {
+#ifdef AFR_FAKE_BMAP      // kernel-development build: arithmetic rows instead of the scalar load (wrong results, timing only)
+        const int k = kbeg + t * BK + wave * 8;
+        return (i32x8){k & 255, (k + 1) & 255, (k + 2) & 255, (k + 3) & 255, (k + 4) & 255, (k + 5) & 255, (k + 6) & 255, (k + 7) & 255};
+#else
+        return *reinterpret_cast<const __attribute__((address_space(4))) i32x8*>(bm_base + t * BK);
+#endif
+    };
+    auto bmap_apply = [&](const i32x8 mv) {
+        const int kr = lane >> 4;
+        const int r0 = kr == 0 ? mv[0] : kr == 1 ? mv[1] : kr == 2 ? mv[2] : mv[3];
+        const int r1 = kr == 0 ? mv[4] : kr == 1 ? mv[5] : kr == 2 ? mv[6] : mv[7];
+        gvb[0] = voffB + (unsigned)r0 * ((unsigned)p.ldb * 2u);
+        gvb[1] = voffB + (unsigned)r1 * ((unsigned)p.ldb * 2u);
+    };
+    auto dma_pair2 = [&](i32x4 rsrc, unsigned lds_a, unsigned voff_a, unsigned voff_b, unsigned soff) {
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 3\n\tbuffer_load_dwordx4 %1, %5, %4 offen lds\n\t"
+                     "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %5, %4 offen lds\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(voff_a), "v"(voff_b), "s"(lds_a), "s"(soff), "s"(rsrc) : "memory");
+    };
     // byte offsets (wave-uniform): per piece row-block, per second sub-tile (+128 rows / +128 elements), per K-tile
     const unsigned pieceA = (ALAY == 0 ? 8u : 4u) * p.lda * 2, pieceB = (BLAY == 0 ? 8u : 4u) * p.ldb * 2;
     const unsigned subA = ALAY == 0 ? 128u * p.lda * 2 : 256u, subB = BLAY == 0 ? 128u * p.ldb * 2 : 256u;
@@ -997,6 +1071,8 @@ __device__ __forceinline__ void gemm_bf16_256_body(const GemmParams& p, const in
             if (q < 2) {
                 const unsigned so = (unsigned)t * tileA + (unsigned)q * subA + i0 * pieceA;
                 dma_pair(rA, lds0 + (sa * 2 + q) * SUB + i0 * 1024, voffA, so, so + pieceA);
+            } else if (GB) {
+                dma_pair2(rB, lds0 + (6 + (t & 1) * 2 + (q - 2)) * SUB + i0 * 1024, gvb[0], gvb[1], (unsigned)(q - 2) * subB);
             } else {
                 const unsigned so = (unsigned)t * tileB + (unsigned)(q - 2) * subB + i0 * pieceB;
                 dma_pair(rB, lds0 + (6 + (t & 1) * 2 + (q - 2)) * SUB + i0 * 1024, voffB, so, so + pieceB);
@@ -1008,7 +1084,7 @@ __device__ __forceinline__ void gemm_bf16_256_body(const GemmParams& p, const in
         for (int i = 0; i < 2; ++i) {
             const int inst = wave * 2 + i;
             if (q < 2) stage_inst<ALAY>(rA, lds0 + (sa * 2 + q) * SUB, p.lda, p.M, m0 + q * 128, k0, kend, inst, lane);
-            else stage_inst<BLAY>(rB, lds0 + (6 + (t & 1) * 2 + (q - 2)) * SUB, p.ldb, p.N, n0 + (q - 2) * 128, k0, kend, inst, lane);
+            else stage_inst<BLAY>(rB, lds0 + (6 + (t & 1) * 2 + (q - 2)) * SUB, p.ldb, p.N, n0 + (q - 2) * 128, k0, kend, inst, lane, GB ? p.b_rowmap : nullptr);
         }
     };
     const bool do_cs = (ALAY == 1) && p.colsum != nullptr && tn == 0;
@@ -1030,8 +1106,8 @@ __device__ __forceinline__ void gemm_bf16_256_body(const GemmParams& p, const in
     };
 
     // prologue: tiles 0 and 1 (what the phases of "tiles -2, -1" would have issued); start when tile 0 has landed
-    if (nt > 0) { stage_sub(0, 0, 0); stage_sub(0, 0, 1); stage_sub(0, 0, 2); stage_sub(0, 0, 3); }
-    if (nt > 1) { stage_sub(1, 1, 0); stage_sub(1, 1, 1); stage_sub(1, 1, 2); stage_sub(1, 1, 3); }
+    if (nt > 0) { if (GB && fast) bmap_apply(bmap_load(0)); stage_sub(0, 0, 0); stage_sub(0, 0, 1); stage_sub(0, 0, 2); stage_sub(0, 0, 3); }
+    if (nt > 1) { if (GB && fast) bmap_apply(bmap_load(1)); stage_sub(1, 1, 0); stage_sub(1, 1, 1); stage_sub(1, 1, 2); stage_sub(1, 1, 3); }
     if (nt > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");     // tile 0 has landed; tile 1 is retired by the wait of phase 3
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -1040,6 +1116,7 @@ __device__ __forceinline__ void gemm_bf16_256_body(const GemmParams& p, const in
 
     bf16x8 fa[2][4], fb[2][4];                          // [k-step][fragment]: A half (64 rows), all 64 B columns
     int sa = 0;                                         // A ring stage of tile t; tile t+2 goes to stage sa + 2 (mod 3)
+    i32x8 mvn = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int t = 0; t < nt; ++t) {
         const char* As = smem + (sa * 2 + wr) * SUB;
         const char* Bs = smem + (6 + (t & 1) * 2 + (wc >> 1)) * SUB;
@@ -1061,6 +1138,10 @@ __device__ __forceinline__ void gemm_bf16_256_body(const GemmParams& p, const in
                     for (int i = 0; i < 4; ++i) fa[ks][i] = read_frag<ALAY>(As, (ph >> 1) * 64 + 16 * i, ks, lane);
             }
             if (ALAY == 1 && do_cs && ph == 1) colsum_tile(smem + sa * 2 * SUB);
+            if (GB && fast && t + 2 < nt) {
+                if (ph == 0) mvn = bmap_load(t + 2);
+                if (ph == 1) bmap_apply(mvn);
+            }
             // ---- this phase's DMA: sub-tile ph of tile t+2
             if (t + 2 < nt && !(ABL & 1)) stage_sub(t + 2, sa2, ph);
             if (ph == 3) {
@@ -1106,7 +1187,7 @@ __device__ __forceinline__ void gemm_bf16_256_body(const GemmParams& p, const in
         }
         __syncthreads();
     }
-    if (p.coop_ws) {
+    if ((ALAY == 1 && BLAY == 1) && p.coop_ws) {      // (weight-gradient products only: both operands k-strided)
         // Cooperative split-K (GemmParams::coop_ws): the S = splitk slice workgroups of this tile exchange their partial
         // sums inside the launch.  Hand-off form (MI355X_MICROARCH.md, visibility table, first row): every payload byte is
         // stored write-through (sc1) and drained by its wave, the workgroup meets at a barrier, ONE lane adds to the tile's
@@ -1123,6 +1204,8 @@ __device__ __forceinline__ void gemm_bf16_256_body(const GemmParams& p, const in
         const __amdgpu_buffer_rsrc_t rws = __builtin_amdgcn_make_buffer_rsrc(p.coop_ws, 0, 0x7FFFFFFF, 0x00020000);
         typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
         const unsigned tile_b = (unsigned)T * (unsigned)S * (8u * 32u * 1024u);          // < 2 GiB: checked by the launcher
+        const bool adam = p.ad_p != nullptr;
+        float* Wt = reinterpret_cast<float*>(smem) + wave * 4096;
         {
             const unsigned mine = tile_b + ((unsigned)z * 8u + (unsigned)wave) * (32u * 1024u) + (unsigned)lane * 16u;
 #pragma unroll
@@ -1131,6 +1214,10 @@ __device__ __forceinline__ void gemm_bf16_256_body(const GemmParams& p, const in
                 for (int j = 0; j < 4; ++j)
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[i][j]), rws, mine + (unsigned)(i * 4 + j) * 1024u, 0, 16);
         }
+        // (Measured and dropped: requesting the first strip's optimizer state by LDS-DMA before / behind the park's stores, so
+        // that it arrives under the park-wait-load chain -- strip_prefetch.  The finish got 4 us shorter, the park and the
+        // wait 7 us longer: this tail is bound by the bytes the whole chip moves at that moment, 32 MB of slices out and in
+        // next to the input-gradient workgroups' 17-34 MB, not by the latency of any one request.)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // every storing wave drains its own stores
         __syncthreads();
         GSTAMP(6);
@@ -1147,22 +1234,21 @@ __device__ __forceinline__ void gemm_bf16_256_body(const GemmParams& p, const in
         }
         __syncthreads();
         GSTAMP(7);
-        float* Wt = reinterpret_cast<float*>(smem) + wave * 4096;
         for (int ii = 0; ii < per; ++ii) {
             const int i = z * per + ii;
-            // all 8 x 4 loads of the strip in flight at once; slices >= S read past the descriptor (zeros): one code path for
-            // every S, and the sum starts from +0 exactly as the slab reduction's does (bitwise equal results)
+            // two rounds of 4 slices (16 loads, 64 VGPRs in flight per lane; more made the kernel spill inside its K loop);
+            // slices >= S read past the descriptor (zeros): one code path for every S, and the sum starts from +0 exactly as
+            // the slab reduction's does (bitwise equal results).  The range check looks at the VGPR offset only.
             const unsigned src = tile_b + (unsigned)wave * (32u * 1024u) + (unsigned)(i * 4) * 1024u + (unsigned)lane * 16u;
             f32x4 v[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {                    // two rounds of 4 slices: 16 loads (64 VGPRs) in flight per lane
+            for (int h = 0; h < 2; ++h) {
                 f32x4 q[4][4];
 #pragma unroll
                 for (int zq = 0; zq < 4; ++zq) {
                     const int zz = 4 * h + zq;
-                    // (the range check looks at the VGPR offset only, so that is where the out-of-range marker goes)
                     const unsigned vo = zz < S ? src + (unsigned)zz * (8u * 32u * 1024u) : 0x80000000u;
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
@@ -1173,7 +1259,7 @@ __device__ __forceinline__ void gemm_bf16_256_body(const GemmParams& p, const in
 #pragma unroll
                     for (int zq = 0; zq < 4; ++zq) v[j] += q[zq][j];
             }
-            strip_finish(p, v, m0 + wr * 128 + 16 * i, n0 + wc * 64, Wt, lane);
+            strip_finish(p, v, m0 + wr * 128 + 16 * i, n0 + wc * 64, Wt, lane, false);
         }
 #ifdef AFR_GEMM_TIMING
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1234,10 +1320,10 @@ __device__ __forceinline__ void gemm_bf16_256_body(const GemmParams& p, const in
 #endif
 }
 
-template <int ALAY, int BLAY, int WM, int ABL = 0>
+template <int ALAY, int BLAY, int WM, int ABL = 0, int GA = 0>
 __global__ __launch_bounds__(128 * WM, 2) void gemm_bf16(GemmParams p) {
     __shared__ __attribute__((aligned(16))) char smem[RingGeom<WM>::LDS_BYTES];
-    gemm_bf16_body<ALAY, BLAY, WM, ABL>(p, blockIdx.x, gridDim.x, smem);
+    gemm_bf16_body<ALAY, BLAY, WM, ABL, GA>(p, blockIdx.x, gridDim.x, smem);
 }
 
 // Several independent products in ONE launch (a layer's weight gradient and input gradient both consume the same dy):
@@ -1268,7 +1354,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_group256(GemmGroup g) {
     const GemmParams& p = g.p[i];
     const int bid = b - g.blk0[i], nblk = g.blk0[i + 1] - g.blk0[i];
     const int lay = ((p.flags & AFR_GEMM_A_KSTRIDED) ? 2 : 0) | ((p.flags & AFR_GEMM_B_KSTRIDED) ? 1 : 0);
-    if (lay == 3) gemm_bf16_256_body<1, 1>(p, bid, nblk, smem);
+    if (lay == 3 && p.b_rowmap) gemm_bf16_256_body<1, 1, 0, 1>(p, bid, nblk, smem);
+    else if (lay == 3) gemm_bf16_256_body<1, 1>(p, bid, nblk, smem);
     else if (lay == 1) gemm_bf16_256_body<0, 1>(p, bid, nblk, smem);
     else if (lay == 0) gemm_bf16_256_body<0, 0>(p, bid, nblk, smem);
     else gemm_bf16_256_body<1, 0>(p, bid, nblk, smem);
@@ -1295,6 +1382,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_lab256(GemmGroup g) {
 // slabs) and the kernel that post-processed its slabs (9 us).
 struct L1BwdArgs {
     const bf16_t* d1; const bf16_t* h0; const bf16_t* W1T; const int64_t* x; const int64_t* font;
+    const int* h0_rowmap;            // optional: glyph b's h0 row is row h0_rowmap[b] of the table h0 (combination table)
     int ldd, ldh, B, N1, vocab, n_fonts;
     int CS, ncols;                   // the N1 columns are cut into CS ranges of ncols (a multiple of 128): block = (row block, range)
     float* slabs; long long slab_stride; int o_b, o_tab;
@@ -1336,7 +1424,7 @@ __global__ __launch_bounds__(512) void glyph_l1_bwd_fused_kernel(L1BwdArgs a) {
         for (int pc = wave; pc < pieces; pc += 8) {
             const int sidx = pc >> 4, inst = pc & 15;
             if (sidx < NS) stage_inst<1>(rD, lds0 + sidx * SUB, a.ldd, a.N1, n_lo + sidx * 128, b0, b0 + nb, inst, lane);
-            else stage_inst<1>(rH, lds0 + NS * SUB, a.ldh, L1_E, 0, b0, b0 + nb, inst, lane);
+            else stage_inst<1>(rH, lds0 + NS * SUB, a.ldh, L1_E, 0, b0, b0 + nb, inst, lane, a.h0_rowmap);
         }
         if (tid < L1_R) {
             long long xi = tid < nb ? a.x[b0 + tid] : 0, fi = (tid < nb && a.n_fonts > 0 && a.font) ? a.font[b0 + tid] : 0;
@@ -1453,6 +1541,11 @@ static bool bf16_use_wide(const GemmParams& p) {
     // 400 narrow ones 302 us); from a full round on the two run level and wide needs fewer L2->LDS bytes
     return t >= 232 && p.K / p.splitk >= 256;      // the 3-stage ring needs a few K-tiles to pay
 }
+bool afr_gemm_wide_ok(int M, int N, int K) {
+    GemmParams q;
+    q.M = M; q.N = N; q.K = K; q.splitk = 1;
+    return bf16_use_wide(q);
+}
 // the symbol rocprofv3 will report for this launch (without the "void bf16k::" decoration)
 const char* afr_gemm_kernel_name(int dtype, const GemmParams& p) {
     const int a = (p.flags & AFR_GEMM_A_KSTRIDED) ? 1 : 0, b = (p.flags & AFR_GEMM_B_KSTRIDED) ? 1 : 0;
@@ -1526,6 +1619,11 @@ hipError_t afr_launch_gemm_group(int dtype, const GemmParams* ps, int n, int til
     if (n <= 0) return hipSuccess;
     bool ok = n <= 4, coop = false;
     for (int i = 0; i < n && ok; ++i) ok = afr_gemm_groupable(dtype, ps[i]);
+    for (int i = 0; i < n; ++i) {          // row gathers a grouped launch supports: B k-strided with A k-strided on 256x256 tiles; aux
+        const bool kk = (ps[i].flags & AFR_GEMM_A_KSTRIDED) && (ps[i].flags & AFR_GEMM_B_KSTRIDED);
+        if (ps[i].a_rowmap || (ps[i].b_rowmap && !(ok && n > 1 && tile256 && kk)) || (ps[i].aux_rowmap && !(ps[i].flags & AFR_GEMM_OUT_BF16)))
+            return hipErrorInvalidValue;
+    }
     for (int i = 0; i < n; ++i) {
         if (!ps[i].coop_ws) continue;
         // cooperative split-K exists in the 256x256 body only, one workgroup per CU, partners resident together
@@ -1566,6 +1664,11 @@ hipError_t afr_launch_gemm(int dtype, const GemmParams& p_in, hipStream_t s) {
 #endif
     const int a = (p.flags & AFR_GEMM_A_KSTRIDED) ? 1 : 0, b = (p.flags & AFR_GEMM_B_KSTRIDED) ? 1 : 0;
     if (p.M <= 0 || p.N <= 0) return hipSuccess;
+    if (p.a_rowmap || p.b_rowmap || p.aux_rowmap) {
+        // row gathers: A k-contiguous on the 256x128 ring kernel; aux with a bf16 output (B: grouped 256x256 launches only)
+        if (dtype != AFR_BF16 || p.b_rowmap || (p.a_rowmap && (a || b || !bf16_use_wide(p))) ||
+            (p.aux_rowmap && !(p.flags & AFR_GEMM_OUT_BF16))) return hipErrorInvalidValue;
+    }
     if (dtype == AFR_BF16) {
         const bool wide = bf16_use_wide(p);
         const int bm = wide ? 256 : 128;
@@ -1610,7 +1713,8 @@ hipError_t afr_launch_gemm(int dtype, const GemmParams& p_in, hipStream_t s) {
             return hipGetLastError();
         }
 #endif
-        if (!a && !b) LB(0, 0);
+        if (p.a_rowmap) hipLaunchKernelGGL((bf16k::gemm_bf16<0, 0, 4, 0, 1>), grid, dim3(512), 0, s, p);
+        else if (!a && !b) LB(0, 0);
         else if (!a && b) LB(0, 1);
         else if (a && !b) LB(1, 0);
         else LB(1, 1);
@@ -1645,10 +1749,11 @@ long long afr_glyph_l1_bwd_fused_slab_floats(int B, int N1, int vocab, int n_fon
     return (long long)nc * bf16k::L1_E + nc + (long long)(vocab + n_fonts) * bf16k::L1_E;
 }
 hipError_t afr_launch_glyph_l1_bwd_fused(const void* d1, int ldd, const void* h0, int ldh, const void* W1T, const int64_t* x,
-                                         const int64_t* font, int B, int N1, int vocab, int n_fonts, float* slabs, hipStream_t s) {
+                                         const int64_t* font, int B, int N1, int vocab, int n_fonts, float* slabs, hipStream_t s,
+                                         const int* h0_rowmap) {
     if (B <= 0) return hipSuccess;
     bf16k::L1BwdArgs a;
-    a.d1 = (const bf16_t*)d1; a.h0 = (const bf16_t*)h0; a.W1T = (const bf16_t*)W1T; a.x = x; a.font = font;
+    a.d1 = (const bf16_t*)d1; a.h0 = (const bf16_t*)h0; a.W1T = (const bf16_t*)W1T; a.x = x; a.font = font; a.h0_rowmap = h0_rowmap;
     a.ldd = ldd; a.ldh = ldh; a.B = B; a.N1 = N1; a.vocab = vocab; a.n_fonts = n_fonts;
     a.CS = afr_glyph_l1_bwd_fused_split(B, N1); a.ncols = N1 / a.CS;
     a.slabs = slabs; a.slab_stride = afr_glyph_l1_bwd_fused_slab_floats(B, N1, vocab, n_fonts);

@@ -263,6 +263,36 @@ def test_c3_cooperative_splitk_equals_slabs_and_separate_launches():
         assert torch.equal(y, e2.forward(xt[:512], ft[:512])), fl
 
 
+@pytest.mark.parametrize("B", [8192, 8008])
+def test_c3_combination_table_first_layer_equals_materialised_h1(B):
+    """A C3 training step does not materialise the first layer's output per glyph: h1 / h0 live as a (character, font)
+    combination table and the second layer's forward, its weight gradient, its ReLU mask and the first layer's backward
+    gather table rows while staging (default).  config.reserved bit 6 = the gather kernel + dense h1 [B][1024].  Same values,
+    same products, same summation order: gradients and three optimizer steps agree bit for bit -- at the bench's batch
+    (every workgroup on the fast addressing path) and at a ragged one (last row block and last K-slice on the slow path)."""
+    from ai_font_renderer_amd.config import WORKLOADS
+    cfg = WORKLOADS["c3"]["cfg"]
+    x, font, tu8 = glyph_inputs(cfg, B)
+    xt, ft, tt = torch.from_numpy(x), torch.from_numpy(font), torch.from_numpy(tu8)
+    a, b = _engine(cfg, dtype="bf16", max_batch=B), _engine(cfg, dtype="bf16", max_batch=B, flags=64)
+    for e in (a, b):
+        e.train_step(xt, tt, font=ft, do_step=False)
+    assert a.read_loss() == b.read_loss()
+    for k in a.grads:
+        assert torch.equal(a.grads[k], b.grads[k]), k
+    for _ in range(3):
+        a.train_step(xt, tt, font=ft)
+        b.train_step(xt, tt, font=ft)
+    assert a.read_loss() == b.read_loss()
+    assert torch.equal(a.flat_params, b.flat_params)
+    assert a.error_flags() == 0 and b.error_flags() == 0
+    # an out-of-range code is flagged by the combination path as by the gather kernel (the reference raises IndexError)
+    xbad = xt.clone()
+    xbad[17] = 128
+    a.train_step(xbad, tt, font=ft, do_step=False)
+    assert a.error_flags() & 1
+
+
 @pytest.mark.parametrize("cfgkw,B,flags", [
     (dict(hidden=(1024, 1024), out_h=32, out_w=32, n_fonts=2), 8192, 0),     # C3: 128 row blocks x 2 column ranges
     (dict(hidden=(1024, 512), out_h=16, out_w=16, n_fonts=2), 1000, 0),      # ragged last block, 4 column ranges
