@@ -14,7 +14,7 @@ AFR_KIND_SHEET, AFR_KIND_GLYPH = 0, 1
 AFR_F32, AFR_BF16 = 0, 1
 AFR_TARGET_U8, AFR_TARGET_F32 = 0, 1
 AFR_MAX_HIDDEN = 8
-BUF_U, BUF_Z, BUF_DZ, BUF_ACT = 0, 1, 2, 16
+BUF_U, BUF_Z, BUF_DZ, BUF_W1T, BUF_W2T, BUF_ACT = 0, 1, 2, 4, 5, 16
 GEMM_BIAS, GEMM_RELU, GEMM_RELU_MASK, GEMM_OUT_BF16, GEMM_A_KSTRIDED, GEMM_B_KSTRIDED = 1, 2, 4, 8, 16, 32
 
 
@@ -57,6 +57,7 @@ SIGNATURES = {
     "afr_profile_read": (_i32, [_vp, C.c_char_p, _i32, C.POINTER(C.c_double), C.POINTER(_i64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "afr_profile_dump": (_i32, [_vp, C.c_char_p, _i32]),
     "afr_debug_copy": (_i32, [_vp, _i32, _vp, _sz, C.POINTER(_sz), _vp]),
+    "afr_debug_sheet_gather": (_i32, [_vp, _vp, _i32, _i32, _vp, _vp]),
     "afr_op_gemm": (_i32, [_i32, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "afr_op_gemm_fix_workspace_bytes": (_sz, [_i32, _i32, _i32, _i32]),
     "afr_op_gemm_fix": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _sz, _vp]),

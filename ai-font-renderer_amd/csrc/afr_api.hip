@@ -1226,6 +1226,11 @@ extern "C" int afr_debug_copy(afr_plan* p, int which, void* dst, size_t cap, siz
     if (which == AFR_BUF_U) { off = p->o_u; bytes = B * c.out_h * c.out_w * ab; }
     else if (which == AFR_BUF_Z && c.kind == AFR_KIND_SHEET) { off = p->o_z; bytes = B * c.max_length * c.fc_dim * ab; }
     else if (which == AFR_BUF_DZ && c.kind == AFR_KIND_SHEET) { off = p->o_dz; bytes = B * c.max_length * c.fc_dim * ab; }
+    else if ((which == AFR_BUF_W1T || which == AFR_BUF_W2T) && p->fused1 && c.dtype == AFR_BF16) {
+        const int N1 = p->layers[0].N, Pix = p->layers[1].N;
+        off = which == AFR_BUF_W1T ? p->o_w1t : p->o_w2t;
+        bytes = (size_t)(which == AFR_BUF_W1T ? c.embed_dim * N1 : N1 * Pix) * 2;
+    }
     else if (which >= AFR_BUF_ACT && c.kind == AFR_KIND_GLYPH && which - AFR_BUF_ACT < (int)p->o_act.size()) {
         const int i = which - AFR_BUF_ACT;
         off = p->o_act[i];
@@ -1234,6 +1239,23 @@ extern "C" int afr_debug_copy(afr_plan* p, int which, void* dst, size_t cap, siz
     if (bytes > cap) return fail(AFR_EINVAL, "destination too small: %zu < %zu", cap, bytes);
     HIPCHK(hipMemcpyAsync(dst, p->ws + off, bytes, hipMemcpyDefault, (hipStream_t)stream));
     if (bytes_out) *bytes_out = bytes;
+    return AFR_OK;
+}
+
+extern "C" int afr_debug_sheet_gather(afr_plan* p, const int64_t* x, int B, int L, float* e0, void* stream) {
+    if (!p || !p->P || !p->ws) return fail(AFR_ESTATE, "plan has no bound parameters");
+    if (p->cfg.kind != AFR_KIND_SHEET) return fail(AFR_EINVAL, "the sheet model's gather: plan is not AFR_KIND_SHEET");
+    if (!x || !e0) return fail(AFR_EINVAL, "x and e0 are required");
+    if (B <= 0 || B > p->cfg.max_batch || L <= 0) return fail(AFR_EINVAL, "batch %d / length %d out of range", B, L);
+    DevGuard dg(p->device);
+    const afr_config& c = p->cfg;
+    const int Lc = L < c.max_length ? L : c.max_length;
+    SheetDims d{Lc, c.max_length, c.embed_dim, c.heads, c.fc_dim, c.vocab};
+    SheetDrop dr = make_drop(p, 0, 0);
+    dr.dbg_e0 = e0;
+    HIPCHK(afr_launch_sheet_fwd(c.dtype, d, sheet_params(p), dr, x, L, B, p->ws + p->o_z, c.ln_eps, (uint32_t*)(p->ws + p->o_err),
+                                (hipStream_t)stream));
+    p->have_du = false;
     return AFR_OK;
 }
 

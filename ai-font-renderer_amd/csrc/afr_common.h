@@ -233,6 +233,9 @@ struct SheetDrop {
     // [4][L][4] (row (h,i), key j: bit (j>>1)&31 of word (j&1)*2 + (j>>6)).  Spares backward the attention recompute
     // and both of its passes the per-element counter hash (3 quarter-rate integer multiplies per probability).
     float* save;
+    // optional inspection output (afr_debug_sheet_gather): the rows the kernel's embedding gather fetched, e0 [B][L][32] f32,
+    // before dropout and positional encoding (model.py:167)
+    float* dbg_e0 = nullptr;
 };
 // offsets (in floats) of the 10 small tensors inside one partial-gradient slab == their flat-buffer offsets
 struct SheetSlabOff { int pos, emb, win, bin, wo, bo, g, b, w1, b1, total; };

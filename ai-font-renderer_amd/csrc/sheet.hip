@@ -34,6 +34,7 @@ constexpr int W_FLOATS = QKV * SE + QKV + E * SE + E + E + E + F * SE + F;   // 
 // LDS buffers sit at fixed offsets sized for the longest supported string (LMAX): a block owns its CU's LDS anyway, and
 // compile-time addresses keep ~15 pointers out of the register file (the backward kernel is register-bound at 128 VGPRs).
 constexpr int LMAX = 120;
+static_assert(LMAX <= 128, "the saved attention-dropout keep bits hold 128 keys per (head, row): 4 words, word (j&1)*2 + (j>>6)");
 constexpr int al4c(int n) { return (n + 3) & ~3; }
 constexpr int O_E = W_FLOATS, O_BIG = O_E + al4c(LMAX * SE), O_O = O_BIG + LMAX * SQ, O_XH = O_O + al4c(LMAX * SE),
               O_DN = O_XH + LMAX * SD, O_RSTD = O_DN + al4c(LMAX * SE), O_SMAX = O_RSTD + al4c(LMAX), O_SINV = O_SMAX + H * LMAX,
@@ -128,6 +129,7 @@ __device__ __forceinline__ void ph_embed(float* e, const int* tok, const SheetPa
     for (int i = tid; i < L * E; i += NT) {
         const int l = i >> 5, c = i & 31;
         float v = P.emb[tok[l] * E + c];
+        if (dr.dbg_e0) dr.dbg_e0[(size_t)b * L * E + i] = v;
         if (dr.training) v = afr_keep((uint64_t)b * L * E + i, dr.key_e, dr.thr_e) ? v * dr.sc_e : 0.f;
         e[l * SE + c] = v + P.pos[i];
     }

@@ -262,15 +262,25 @@ class Engine:
 
     def debug_read(self, which, index=0):
         """Copy an internal activation buffer of the last call (u/du, z, dz, glyph activation i) as float32."""
-        code = {"u": _lib.BUF_U, "z": _lib.BUF_Z, "dz": _lib.BUF_DZ, "act": _lib.BUF_ACT + int(index)}[which]
-        dt = torch.bfloat16 if self.dtype in ("bf16", "bfloat16") else torch.float32
+        code = {"u": _lib.BUF_U, "z": _lib.BUF_Z, "dz": _lib.BUF_DZ, "act": _lib.BUF_ACT + int(index), "w1t": _lib.BUF_W1T, "w2t": _lib.BUF_W2T}[which]
+        dt = torch.bfloat16 if (self.dtype in ("bf16", "bfloat16") or which in ("w1t", "w2t")) else torch.float32
         es = 2 if dt == torch.bfloat16 else 4
-        cap = self.max_batch * max(self.pixels, getattr(self.cfg, "flat_dim", 0), *(getattr(self.cfg, "hidden", (0,))), self.cfg.embed_dim) * es
+        cap = max(self.max_batch * max(self.pixels, getattr(self.cfg, "flat_dim", 0), *(getattr(self.cfg, "hidden", (0,))), self.cfg.embed_dim) * es, 1 << 20)
         buf = torch.empty(cap, dtype=torch.uint8, device=self.device)
         n = C.c_size_t()
         self._call(self.lib.afr_debug_copy, self._plan, code, _ptr(buf), cap, C.byref(n))
         torch.cuda.synchronize(self.device)
         return buf[:n.value].view(dt).float()
+
+    def debug_sheet_gather(self, x):
+        """The rows the sheet front end's in-kernel embedding gather fetched for x [B, L]: float32 [B, min(L, max_length), E]."""
+        x, _ = self._prep_x(x, None)
+        self.ensure_batch(x.shape[0])
+        B, L = x.shape
+        e0 = torch.full((B, min(L, self.cfg.max_length), self.cfg.embed_dim), float("nan"), dtype=torch.float32, device=self.device)
+        self._call(self.lib.afr_debug_sheet_gather, self._plan, _ptr(x), B, L, _ptr(e0))
+        torch.cuda.synchronize(self.device)
+        return e0
 
     # ---------------------------------------------------------------- measurement
     def profile(self, mode=1):

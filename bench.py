@@ -74,6 +74,18 @@ def host_cores():
     return int(os.environ.get("AFR_CPU_THREADS", min(n, 16)))
 
 
+def reference_bitmap_diff(cfg, sample):
+    """The metric's second half: max-abs difference between the bitmaps the engine drew (sample["y"], its benchmarked dtype)
+    and the unrounded f32 CPU reference path on the SAME f32 master weights and inputs (the oracle: checker only)."""
+    from oracle import afr_oracle as oracle            # checker / baseline only -- never on the product path
+    P = sample["params"]
+    if isinstance(cfg, SheetConfig):
+        yref, _ = oracle.sheet_forward(P, sample["x"], cfg)
+    else:
+        yref, _ = oracle.glyph_forward(P, sample["x"], sample["font"], cfg)
+    return float((sample["y"].reshape(yref.shape) - yref).abs().max())
+
+
 def cpu_baseline(name, cfg, B, budget_s=12.0):
     """The oracle (a CPU port of the reference's step in plain torch ops) timed on this box's host cores."""
     from oracle import afr_oracle as oracle            # checker / baseline only -- never on the product path
@@ -108,17 +120,25 @@ def cpu_baseline(name, cfg, B, budget_s=12.0):
                           "tests/golden/cpu_step_times.json, made by tests/golden/make_golden.py cpu_step_times"}
 
 
+PROFILE_ROUND = "r03"      # the round whose committed PMC passes describe THIS code (profiles/<round>/pmc_traffic.json)
+
+
 def pmc_traffic(workload, kernel):
-    """HBM bytes per launch of `kernel` from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE run
-    separately on this same command; FETCH doubled per the gfx950 rule; tools/pmc_summary.py), or None."""
-    for rnd in ("r02", "r01"):
-        path = os.path.join(ROOT, "profiles", rnd, "pmc_traffic.json")
-        try:
-            d = json.load(open(path))[workload][kernel]
-            return d["read_bytes"] + d["write_bytes"], f"profiles/{rnd}/pmc_traffic.json"
-        except Exception:
-            continue
-    return None, None
+    """HBM bytes per launch of `kernel` from THIS round's committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE run
+    separately on this same command; FETCH doubled per the gfx950 rule; tools/pmc_summary.py).  No file for this round:
+    (None, reason) -- never an older round's numbers.  File present but the kernel missing from it: an error (the engine
+    reports "gemm_bf16<1,1,2>", rocprofv3 the full template argument list "gemm_bf16<1,1,2,0,0>": matched on that prefix)."""
+    rel = f"profiles/{PROFILE_ROUND}/pmc_traffic.json"
+    path = os.path.join(ROOT, rel)
+    if not os.path.exists(path):
+        return None, f"no PMC passes committed for {PROFILE_ROUND} yet"
+    table = json.load(open(path)).get(workload, {})
+    stem = kernel[:-1] if kernel.endswith(">") else kernel
+    hits = [k for k in table if k == kernel or (kernel.endswith(">") and k.startswith(stem) and k[len(stem):len(stem) + 1] in (",", ">"))]
+    if len(hits) != 1:
+        raise SystemExit(f"{rel}: kernel {kernel!r} of workload {workload!r} matches {hits or 'nothing'} (keys: {sorted(table)})")
+    d = table[hits[0]]
+    return d["read_bytes"] + d["write_bytes"], rel
 
 
 PREHEAT_MS = 30.0
@@ -154,7 +174,7 @@ def spawn_ranks(n, argv):
     return subprocess.run(cmd, env=env).returncode
 
 
-def measure(name, dtype, B, K, W, rank, world, dist, with_roofline=True):
+def measure(name, dtype, B, K, W, rank, world, dist, with_roofline=True, want_sample=False):
     """W warm-up steps, then exactly K timed steps between fences.  Returns (engine, elapsed_s, dominant, table, loss)."""
     from ai_font_renderer_amd.engine import Engine
     from ai_font_renderer_amd.parallel import DataParallelStepper
@@ -217,7 +237,13 @@ def measure(name, dtype, B, K, W, rank, world, dist, with_roofline=True):
         elapsed = float(tt.item())
     loss = eng.read_loss() / max(K + W, 1)
     if eng.error_flags():
-        raise SystemExit("device error flag set (embedding index out of range)")
+        raise SystemExit("device error flag set (embedding index out of range / cooperative split-K timeout)")
+    # a sample of the bitmaps the trained engine draws, with its f32 master weights, for the max-abs-diff leg (rank 0, CPU side)
+    if rank == 0 and want_sample:
+        ns = min(B, 16 if isinstance(cfg, SheetConfig) else 190)
+        xs, fs = x[:ns], (font[:ns] if font is not None else None)
+        eng.sample = {"x": xs.cpu(), "font": fs.cpu() if fs is not None else None, "y": eng.forward(xs, fs).cpu(),
+                      "params": {k: v.cpu() for k, v in eng.state_dict().items()}}
     return eng, elapsed, dom, table, loss
 
 
@@ -262,7 +288,18 @@ def main():
         else:
             dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
 
-    eng, elapsed, dom, table, loss = measure(name, dtype, B, K, W, rank, world, dist)
+    # from cold first (no pre-heat forwards; the process has done next to no GPU work so far), then the steady-state run
+    cold_ms = None
+    if args.preheat_ms > 0 and not args.no_extras:
+        PREHEAT_MS = 0.0
+        e0, el0, _, _, _ = measure(name, dtype, B, K, W, rank, world, dist, with_roofline=False)
+        cold_ms = el0 / K * 1e3
+        del e0
+        torch.cuda.empty_cache()
+        PREHEAT_MS = args.preheat_ms
+    want_diff = world == 1 and not args.no_cpu_baseline
+    eng, elapsed, dom, table, loss = measure(name, dtype, B, K, W, rank, world, dist, want_sample=want_diff)
+    samples = {dtype: getattr(eng, "sample", None)}
 
     if rank == 0:
         value = world * B * K / elapsed
@@ -276,14 +313,16 @@ def main():
         peak_fl = PEAK["f32"] if f32_kernel else PEAK[dtype]           # f32 VALU peak == f32 MFMA peak (157.3 TF)
         fl = dom["algo_flops"] / secs / 1e12
         by = dom["algo_bytes"] / secs / 1e9
-        hbm_bound = dom["algo_flops"] <= 0 or (name == "r0" and dtype == "bf16" and kern.startswith("gemm_bf16<1,1"))
+        # which roof binds the dominant kernel: the one it is closer to (R0's bf16 weight-gradient GEMM with the fused optimizer
+        # moves 26 B of p/m/v per output element and sits at 0.55 of HBM against 0.14 of MFMA; C3's products the other way)
+        hbm_bound = dom["algo_flops"] <= 0 or by / HBM_PEAK_GBS > fl / peak_fl
         if hbm_bound:
             roof = {"bound": "hbm", "kernel": kern, "achieved": by, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": by / HBM_PEAK_GBS}
         else:
             # every dense product of the path runs on the matrix cores (the f32 forms at the f32 VALU's rate, 157.3 TF)
             roof = {"bound": "mfma", "kernel": kern, "achieved": fl, "peak": peak_fl, "unit": "TFLOP/s", "frac": fl / peak_fl}
         tr, src = pmc_traffic(name, kern) if (dtype == DEFAULT_DTYPE[name] and not args.batch) else (None, None)
-        roof.update({"traffic": tr, "traffic_unit": f"bytes/launch (PMC FETCH_SIZE x2 + WRITE_SIZE, {src})" if src else None,
+        roof.update({"traffic": tr, "traffic_unit": f"bytes/launch (PMC FETCH_SIZE x2 + WRITE_SIZE, {src})" if tr is not None else src,
                      "avg_launch_ms": dom["avg_ms"], "launches": dom["launches"], "algo_flops_per_launch": dom["algo_flops"],
                      "algo_bytes_per_launch": dom["algo_bytes"], "mfma_frac": fl / peak_fl if dom["algo_flops"] > 0 else None,
                      "hbm_frac": by / HBM_PEAK_GBS})
@@ -311,7 +350,7 @@ def main():
         out = {
             "metric": "glyphs/sec training (batch fwd+bwd+step)", "value": value, "unit": "glyphs/s", "n_gpus": world,
             "steps": K, "warmup": W, "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": dtype, "data": "synthetic", "preheat_ms": PREHEAT_MS,
+            "vs_baseline": None, "dtype": dtype, "data": "synthetic", "preheat_ms": PREHEAT_MS, "cold_ms_per_step": cold_ms,
             "config": {"workload": DESCR[name], "per_gpu_batch": B, "global_batch": world * B,
                        "parallelism": f"dp{world}" if world > 1 else "single", "params": int(sum(n for _, _, _, n in eng.layout)),
                        "mean_loss": loss},
@@ -326,7 +365,9 @@ def main():
         if not args.no_extras and not args.batch:
             # parity mode of the SAME config (exact-f32 MFMA everywhere: the mode that meets the 1e-4 bitmap bar)
             if dtype != "f32":
-                _, el, _, _, _ = measure(name, "f32", B, max(5, K // 4), 3, 0, 1, None, with_roofline=False)
+                ep, el, _, _, _ = measure(name, "f32", B, max(5, K // 4), 3, 0, 1, None, with_roofline=False, want_sample=want_diff)
+                samples["f32"] = getattr(ep, "sample", None)
+                del ep
                 kk = max(5, K // 4)
                 out["parity_mode"] = {"dtype": "f32", "ms_per_step": el / kk * 1e3, "value": B * kk / el, "unit": "glyphs/s", "steps": kk,
                                       "note": "same workload with f32 operands (v_mfma_f32_32x32x2_f32); bitmaps within 2e-5 of the reference"}
@@ -344,6 +385,14 @@ def main():
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(name, cfg, B)
             out["cpu_baseline"]["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
+            # max-abs bitmap diff vs the CPU reference path, for the benchmarked dtype and for the parity mode
+            note = ("engine eval forward after the run's training steps vs the f32 oracle on the engine's own f32 master weights; "
+                    "%d samples; tests assert <= 2.5e-2 (bf16) / 2e-5 (f32): tests/test_gpu_models.py")
+            if samples.get(dtype):
+                out["max_abs_bitmap_diff"] = {"value": reference_bitmap_diff(cfg, samples[dtype]), "dtype": dtype,
+                                              "note": note % samples[dtype]["y"].shape[0]}
+            if samples.get("f32") and "parity_mode" in out:
+                out["parity_mode"]["max_abs_bitmap_diff"] = reference_bitmap_diff(cfg, samples["f32"])
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:

@@ -166,8 +166,15 @@ int afr_profile_dump(afr_plan* plan, char* buf, int cap);
 enum { AFR_BUF_U = 0,      /* pre-clamp output u [B, pixels]; after afr_loss_grad it holds du                     */
        AFR_BUF_Z = 1,      /* sheet: flattened fc1 features z [B, max_length*fc_dim]                               */
        AFR_BUF_DZ = 2,     /* sheet: gradient w.r.t. z                                                            */
+       AFR_BUF_W1T = 4,    /* small glyph nets, bf16: the transposed operand copy W1^T [E][N1] the fused step reads */
+       AFR_BUF_W2T = 5,    /*                         and W2^T [N1][pixels] (always bf16)                          */
        AFR_BUF_ACT = 16 }; /* glyph: AFR_BUF_ACT + i = activation i (0 = embedding sum, i = output of hidden i)   */
 int afr_debug_copy(afr_plan* plan, int which, void* dst, size_t dst_bytes, size_t* bytes_out, void* stream);
+/* Inspection of the sheet model's in-kernel embedding gather (model.py:136,167): runs the front end of an eval forward on
+ * x [B, L] and leaves the rows it gathered, Emb[x[b][l]] for l < min(L, max_length), in e0 (device, float32
+ * [B][min(L, max_length)][embed_dim]) -- before dropout and the positional encoding.  The north star asks this gather to
+ * be bit-exact; the glyph nets expose theirs as AFR_BUF_ACT + 0. */
+int afr_debug_sheet_gather(afr_plan* plan, const int64_t* x, int B, int L, float* e0, void* stream);
 
 /* ---- single-kernel entry points (unit tests and re-use by callers either side of the path) ---- */
 enum { AFR_GEMM_BIAS = 1, AFR_GEMM_RELU = 2, AFR_GEMM_RELU_MASK = 4, AFR_GEMM_OUT_BF16 = 8,

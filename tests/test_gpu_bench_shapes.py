@@ -441,3 +441,34 @@ def test_fused_small_net_step_equals_the_per_layer_kernels(cfgkw, B, dtype):
     g1 = a.flat_grads.clone()
     a.train_step(xt, tt, font=ft, do_step=False)
     assert torch.equal(g1, a.flat_grads)
+
+
+@pytest.mark.parametrize("workload", ["c2", "c1"])
+def test_fused_small_net_bf16_transposed_copies_stay_current(workload):
+    """bf16 fused small-net step (C1 / C2, the benchmarked path): the transposed operand copies W1^T / W2^T that the NEXT
+    step's dh1 = du . W2^T and dh0 = dpre1 . W1^T read are written by the grouped reduce's AdamW epilogue (shT scatter) and
+    cached behind wT_valid.  Three fused steps against three steps with the optimizer un-fused (config.reserved bit 0:
+    wT_valid = false, a fresh transpose kernel every step): parameters, moments and the last step's gradients bit for bit;
+    and the copies read back through afr_debug_copy equal transpose(bf16(P))."""
+    from ai_font_renderer_amd.config import WORKLOADS
+    cfg, B = WORKLOADS[workload]["cfg"], WORKLOADS[workload]["batch"]
+    x, font, tu8 = glyph_inputs(cfg, B)
+    xt, tt = torch.from_numpy(x), torch.from_numpy(tu8)
+    a, b = _engine(cfg, dtype="bf16", max_batch=B), _engine(cfg, dtype="bf16", max_batch=B, flags=1)
+    for _ in range(3):
+        a.train_step(xt, tt)
+        b.train_step(xt, tt)
+    assert a.read_loss() == b.read_loss()
+    assert torch.equal(a.flat_params, b.flat_params)
+    assert torch.equal(a.exp_avg, b.exp_avg) and torch.equal(a.exp_avg_sq, b.exp_avg_sq)
+    N1, P = cfg.hidden[0], cfg.pixels
+    for eng in (a, b):
+        w1t = eng.debug_read("w1t").view(cfg.embed_dim, N1).cpu()
+        w2t = eng.debug_read("w2t").view(N1, P).cpu()
+        if eng is b:                               # un-fused: the copies are those the LAST step's transpose made, one AdamW behind
+            continue
+        assert torch.equal(w1t, eng.params["fc1.weight"].cpu().to(torch.bfloat16).float().t())
+        assert torch.equal(w2t, eng.params["fc_output.weight"].cpu().to(torch.bfloat16).float().t())
+    a.train_step(xt, tt, do_step=False)             # a fourth step's gradients read the copies the third step's reduce wrote
+    b.train_step(xt, tt, do_step=False)
+    assert torch.equal(a.flat_grads, b.flat_grads)

@@ -145,3 +145,48 @@ def test_opt_in_bf16_gradient_exchange_tracks_the_exact_exchange(monkeypatch):
         assert torch.equal(eng.flat_params, eng2.flat_params)
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("kind,dtype", [("glyph", "f32"), ("glyph", "bf16"), ("sheet", "f32"), ("sheet", "bf16")])
+def test_sharded_optimizer_schedule_over_rccl_world1(kind, dtype, monkeypatch):
+    """The sharded-optimizer schedule (opt-in, AFR_DP_SCHEDULE=shard; here shard-force so that it runs at a world of one):
+    in-place RCCL reduce_scatter_tensor -> Engine.adamw_range (afr_op_adamw on an offset slice of p/g/m/v) -> in-place
+    all_gather_into_tensor -> shadow re-sync.  Three steps give bit-identical parameters and moments to the replicated
+    path (one all-reduce + afr_adamw_step), in both dtypes, for a glyph net and the mini sheet model."""
+    import torch.distributed as dist
+    from ai_font_renderer_amd.engine import Engine
+    from ai_font_renderer_amd.parallel import DataParallelStepper
+    from .util import MINI
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", str(29600 + os.getpid() % 300))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        def make():
+            if kind == "glyph":
+                cfg, eng = _glyph_engine(dtype=dtype)
+                x, font, t = glyph_inputs(cfg, 300)
+                return cfg, eng, torch.from_numpy(x).cuda(), torch.from_numpy(font).cuda(), torch.from_numpy(t).cuda(), 300
+            eng = Engine(MINI, dtype=dtype, max_batch=64)
+            eng.load_params(synth.make_params(MINI))
+            x = torch.from_numpy(synth.encode_strings(synth.dataset_strings(37), MINI.max_length)).cuda()
+            t = torch.from_numpy(synth.synth_sheet_targets(37, MINI.sheet_h, MINI.sheet_w, tensor_id=931)).cuda()
+            return MINI, eng, x, None, t, 37
+        out = {}
+        for sched in ("shard-force", "replicated"):
+            if sched == "shard-force":
+                monkeypatch.setenv("AFR_DP_SCHEDULE", "shard-force")
+            else:
+                monkeypatch.delenv("AFR_DP_SCHEDULE", raising=False)
+            cfg, eng, xt, ft, tt, B = make()
+            st = DataParallelStepper(eng, dist, world=1 if sched == "shard-force" else 2)     # 2: forced multi-rank replicated path
+            assert st.sharded() == (sched == "shard-force")
+            for i in range(3):
+                st.step(xt, tt, ft, mean_elems=B * cfg.pixels, step=i + 1)
+            y = eng.forward(xt, ft)                      # reads the bf16 shadow in bf16 mode: it was re-synced
+            out[sched] = (st.global_loss(), eng.flat_params.clone(), eng.exp_avg.clone(), eng.exp_avg_sq.clone(), y.clone())
+        a, b = out["shard-force"], out["replicated"]
+        assert a[0] == b[0]
+        for u, v in zip(a[1:], b[1:]):
+            assert torch.equal(u, v)
+    finally:
+        dist.destroy_process_group()

@@ -67,6 +67,7 @@ def _worker(rank, world, port, q, shard=False):
     from ai_font_renderer_amd.parallel import DataParallelStepper, shard_rows
     if shard:
         parallel.SHARD_MIN_BYTES = 0          # take the sharded-optimizer schedule for this small net too
+        os.environ["AFR_DP_SCHEDULE"] = "shard"   # (opt-in until a multi-GPU node has run it)
     else:
         parallel.SHARD_MIN_BYTES = 1 << 60
     torch.set_num_threads(1)
