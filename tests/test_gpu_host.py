@@ -172,19 +172,22 @@ def test_train_string_renderer_end_to_end(tmp_path, monkeypatch):
     assert (tmp_path / "render_only" / "string_0.bmp").exists()
 
 
-@pytest.mark.parametrize("run", ["a", "b"])
+@pytest.mark.parametrize("run", ["a", "b", "c"])
 def test_training_loop_replays_the_references_own_trajectory(tmp_path, monkeypatch, capsys, run):
     """train_attention_model against tests/golden/train_loop.npz: the REFERENCE's train_attention_model (model.py:209-384)
     run on the same 80 sheets with the same constants.  Same split, same batch order, same mean-of-batch-means, same
     scheduler and early-stopping decisions: per-epoch validation loss and learning rate, the printed train losses,
-    training_results.txt and (run a) the final parameters."""
+    training_results.txt and (run a) the final parameters.  Run a never changes its rate, run b saturates (constant
+    validation loss) and is stopped early; run c is the one whose ReduceLROnPlateau cuts the rate twice WHILE the loss
+    still falls (0.35 -> 0.085 in 10 epochs): every epoch after a cut trains with live gradients at the new rate."""
     from dataclasses import replace
     from ai_font_renderer_amd import model as M
     from ai_font_renderer_amd.engine import Engine
     fx = load("train_loop.npz")
     lr0 = float(fx[run + "/lrs"][0])
+    sched_pat, stop_pat, n_epochs = (int(v) for v in fx[run + "/patience"])
     monkeypatch.chdir(tmp_path)
-    for k, v in dict(NUM_EPOCHS=16, LEARNING_RATE=lr0, SCHEDULER_PATIENCE=1, EARLY_STOPPING_PATIENCE=4, OUTPUT_DIR="loop_out",
+    for k, v in dict(NUM_EPOCHS=n_epochs, LEARNING_RATE=lr0, SCHEDULER_PATIENCE=sched_pat, EARLY_STOPPING_PATIENCE=stop_pat, OUTPUT_DIR="loop_out",
                      SHEET_HEIGHT=8, SHEET_WIDTH=24, MAX_CHARS_PER_SHEET=10).items():
         monkeypatch.setattr(M, k, v)
     m = M.AttentionFontRenderer(max_length=10, max_batch=16, init=False)
@@ -208,16 +211,31 @@ def test_training_loop_replays_the_references_own_trajectory(tmp_path, monkeypat
     monkeypatch.setattr(Sched, "step", step)
     M.train_attention_model(m, ds, 16)
     val, lrs = np.array([v for v, _ in log]), np.array([l for _, l in log])
+    print(run, "val", val.tolist(), "lrs", lrs.tolist())
     assert len(val) == len(fx[run + "/val_losses"])                      # same number of epochs: same stopping decision
     assert np.allclose(lrs, fx[run + "/lrs"], rtol=1e-12)                # same plateau decisions
-    assert np.abs(val / fx[run + "/val_losses"] - 1).max() < 1e-4
+    # (run c: 4x run a's rate, the loss halves in one epoch and then oscillates -- a regime that amplifies rounding: the two f32
+    # implementations agree to 4e-7 after two epochs, 2e-4 after three, 2 % after ten.  What run c pins is the DECISIONS (the
+    # learning-rate sequence, exactly; their margins are 2 % and more) and that the trajectories stay together to that order.)
+    assert np.abs(val / fx[run + "/val_losses"] - 1).max() < (4e-2 if run == "c" else 1e-4)
+    if run == "c":
+        assert np.abs(val[:3] / fx["c/val_losses"][:3] - 1).max() < 5e-4
+    if run == "c":
+        lr_ref, v_ref = fx["c/lrs"], fx["c/val_losses"]
+        cuts = [i for i in range(1, len(lr_ref)) if lr_ref[i] < lr_ref[i - 1]]
+        assert len(cuts) >= 2 and all(abs(val[i + 1] / val[i] - 1) > 1e-2 for i in cuts)      # live loss behind each cut
     out = capsys.readouterr().out
     printed = {int(l.split(",")[0].split()[1]): float(l.split("Train Loss:")[1].split(",")[0]) for l in out.splitlines()
                if l.startswith("Epoch ") and "Train Loss:" in l}
     assert sorted(printed) == list(fx[run + "/printed_epochs"])
-    assert np.abs(np.array([printed[e] for e in sorted(printed)]) / fx[run + "/printed_train_losses"] - 1).max() < 2e-4
+    assert np.abs(np.array([printed[e] for e in sorted(printed)]) / fx[run + "/printed_train_losses"] - 1).max() < (4e-2 if run == "c" else 2e-4)
     res = [l for l in (tmp_path / "loop_out" / "training_results.txt").read_text().splitlines() if not l.startswith("training_completed")]
-    assert res == str(fx[run + "/results"]).splitlines()
+    want = str(fx[run + "/results"]).splitlines()
+    if run == "c":       # best_validation_loss is printed to 6 decimals: equal to the trajectory tolerance, every other line exactly
+        num = lambda ls: float([l for l in ls if l.startswith("best_validation_loss")][0].split("=")[1])
+        assert abs(num(res) / num(want) - 1) < 4e-2
+        res, want = [l for l in res if not l.startswith("best_validation_loss")], [l for l in want if not l.startswith("best_validation_loss")]
+    assert res == want
     if run == "a":
         E = MINI.embed_dim
         for k, v in m.state_dict().items():
