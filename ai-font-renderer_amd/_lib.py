@@ -68,6 +68,8 @@ SIGNATURES = {
     "afr_op_adamw": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _i64, _f32, _vp]),
     "afr_op_mse_grad": (_i32, [_i32, _vp, _vp, _i32, _vp, _i64, _i64, _i64, _vp, _vp, _vp]),
     "afr_op_f32_to_bf16": (_i32, [_vp, _vp, _i64, _vp]),
+    "afr_op_f32_to_fp8": (_i32, [_vp, _vp, _i64, _f32, _vp]),
+    "afr_op_gemm_fp8": (_i32, [_i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp]),
 }
 
 

@@ -1398,3 +1398,24 @@ extern "C" int afr_op_f32_to_bf16(const float* src, void* dst, int64_t n, void* 
     HIPCHK(afr_launch_f32_to_bf16(src, (bf16_t*)dst, n, (hipStream_t)stream));
     return AFR_OK;
 }
+extern "C" int afr_op_f32_to_fp8(const float* src, void* dst, int64_t n, float scale, void* stream) {
+    if (!src || !dst || n < 0 || !(scale > 0.f)) return fail(AFR_EINVAL, "bad f32 -> fp8 arguments");
+    DevGuard dg(device_of(dst));
+    HIPCHK(afr_launch_f32_to_fp8(src, (unsigned char*)dst, n, 1.f / scale, (hipStream_t)stream));
+    return AFR_OK;
+}
+extern "C" int afr_op_gemm_fp8(int flags, const void* A, const void* B, void* C, const float* bias, int M, int N, int K, int lda, int ldb,
+                               int ldc, float scale_ab, void* stream) {
+    if (!A || !B || !C) return fail(AFR_EINVAL, "null operand");
+    if (M <= 0 || N <= 0 || K <= 0) return fail(AFR_EINVAL, "bad GEMM extents");
+    if (flags & ~(AFR_GEMM_BIAS | AFR_GEMM_RELU | AFR_GEMM_OUT_BF16)) return fail(AFR_EUNSUPPORTED, "fp8 products take bias / relu / bf16-output only (both operands k-contiguous)");
+    if ((flags & AFR_GEMM_BIAS) && !bias) return fail(AFR_EINVAL, "bias flag without a bias");
+    if (K % 16 || lda % 16 || ldb % 16 || N % 8 || ldc % 8) return fail(AFR_EUNSUPPORTED, "K, lda, ldb must be multiples of 16; N, ldc of 8");
+    if ((long long)M * lda >= (1ll << 31) || (long long)N * ldb >= (1ll << 31)) return fail(AFR_EUNSUPPORTED, "an fp8 GEMM operand must be smaller than 2 GiB");
+    DevGuard dg(device_of(C));
+    GemmParams g;
+    g.A = A; g.B = B; g.C = C; g.bias = bias; g.aux = nullptr; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.ldaux = 0;
+    g.flags = flags; g.splitk = 1; g.slab_stride = 0; g.out_scale = scale_ab;
+    HIPCHK(afr_launch_gemm_fp8(g, (hipStream_t)stream));
+    return AFR_OK;
+}

@@ -130,6 +130,7 @@ struct GemmParams {
     // table (elementwise.hip glyph_combo_kernel).  Supported: A k-contiguous on the 256x128 ring kernel, B k-strided on the
     // 256x256 kernel, aux with a bf16 output; the launchers refuse anything else.
     const int* a_rowmap = nullptr; const int* b_rowmap = nullptr; const int* aux_rowmap = nullptr;
+    float out_scale = 1.f;     // fp8 products: scale_a * scale_b, applied to the accumulators ahead of bias / ReLU
 #ifdef AFR_GEMM_TIMING
     int dbg_slot = 0;     // kernel-development builds: which 1024-block region of the stamp buffer this launch writes
 #endif
@@ -145,6 +146,8 @@ __device__ __forceinline__ void adamw_elem(float& p, float& m, float& v, float g
     p -= step_size * (m / denom);
 }
 hipError_t afr_launch_gemm(int dtype, const GemmParams& p, hipStream_t s);
+hipError_t afr_launch_gemm_fp8(const GemmParams& p, hipStream_t s);          // e4m3 x e4m3, both k-contiguous (gemm.hip fp8k)
+hipError_t afr_launch_f32_to_fp8(const float* src, unsigned char* dst, long long n, float inv_scale, hipStream_t s);
 // several independent products in one launch (falls back to one launch each when one of them does not qualify)
 bool afr_gemm_groupable(int dtype, const GemmParams& p);
 hipError_t afr_launch_gemm_group(int dtype, const GemmParams* ps, int n, int tile256, hipStream_t s);

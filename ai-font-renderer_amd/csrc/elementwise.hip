@@ -217,6 +217,32 @@ hipError_t afr_launch_f32_to_bf16(const float* src, bf16_t* dst, long long n, hi
     return hipGetLastError();
 }
 
+// -------------------------------------------------------------------------------- f32 -> fp8
+// dst = e4m3(src * inv_scale), OCP e4m3fn (gfx950's native fp8: bias 7, max 448, no infinities), round to nearest even,
+// saturating at +-448.  The per-tensor scale is the caller's (max |src| / 448 is the usual choice).
+__global__ __launch_bounds__(256) void f32_to_fp8_kernel(const float* __restrict__ src, unsigned char* __restrict__ dst, long long n,
+                                                         float inv_scale) {
+    const long long n4 = n >> 2;
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        const float4 a = reinterpret_cast<const float4*>(src)[i];
+        const float x0 = fminf(fmaxf(a.x * inv_scale, -448.f), 448.f), x1 = fminf(fmaxf(a.y * inv_scale, -448.f), 448.f);
+        const float x2 = fminf(fmaxf(a.z * inv_scale, -448.f), 448.f), x3 = fminf(fmaxf(a.w * inv_scale, -448.f), 448.f);
+        int w = 0;
+        w = __builtin_amdgcn_cvt_pk_fp8_f32(x0, x1, w, false);
+        w = __builtin_amdgcn_cvt_pk_fp8_f32(x2, x3, w, true);
+        reinterpret_cast<int*>(dst)[i] = w;
+    }
+    for (long long i = (n4 << 2) + blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const float x = fminf(fmaxf(src[i] * inv_scale, -448.f), 448.f);
+        dst[i] = (unsigned char)(__builtin_amdgcn_cvt_pk_fp8_f32(x, x, 0, false) & 0xFF);
+    }
+}
+hipError_t afr_launch_f32_to_fp8(const float* src, unsigned char* dst, long long n, float inv_scale, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(f32_to_fp8_kernel, dim3(grid_for((n + 3) / 4, 256)), dim3(256), 0, s, src, dst, n, inv_scale);
+    return hipGetLastError();
+}
+
 // -------------------------------------------------------------------- clamp output (eval path)
 // y = clamp(u, 0, 1) as float32: the model's output activation (reference model.py:156,202)
 template <typename T>

@@ -347,7 +347,7 @@ __device__ unsigned long long* g_gemm_stamps = nullptr;
 #endif
 // The epilogue of one wave's 64x64 f32 accumulator tile whose top-left element is (mb, nb0) of the product; Wt = the
 // wave's own 16 KiB of LDS.  Shared by the 256x128 / 128x128 kernels (one call) and the 256x256 kernel (two calls).
-template <int ALAY, int BLAY, int WM>
+template <int ALAY, int BLAY, int WM, bool SCALE = false>      // SCALE: the accumulators are multiplied by p.out_scale first (fp8 per-tensor scales)
 __device__ __forceinline__ void wave_epilogue(const GemmParams& p, const f32x4 (&acc)[4][4], const int mb, const int nb0, const int z,
                                               float* Wt, const int lane, float& lsum, const float* lut255 = nullptr) {
     // Epilogue through LDS: the MFMA accumulators hold 4 consecutive n of 16 different rows per lane-group, which as
@@ -365,6 +365,7 @@ __device__ __forceinline__ void wave_epilogue(const GemmParams& p, const f32x4 (
             const int nl = 16 * j + 4 * (lane >> 4);
             const int n = nb0 + nl;
             f32x4 v = acc[i][j];
+            if (SCALE) v *= p.out_scale;
             if ((flags & AFR_GEMM_BIAS) && n < p.N) {
                 const float4 bb = *reinterpret_cast<const float4*>(p.bias + n);
                 v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
@@ -1514,6 +1515,127 @@ __global__ __launch_bounds__(512) void glyph_l1_bwd_fused_kernel(L1BwdArgs a) {
 #endif
 }
 }  // namespace bf16k
+
+// ------------------------------------------------------------------------------------------ fp8
+// C[m][n] = scale * sum_k A(m,k) B(n,k) (+bias) (relu), A and B OCP e4m3 bytes, both k-contiguous (the forward form x . W^T),
+// f32 accumulation on v_mfma_scale_f32_16x16x128_f8f6f4 with unit block scales: the MX-scaled instruction is the one that runs
+// fp8 at twice the bf16 rate (5 PF dense; the plain fp8 MFMAs run at the bf16 rate) -- `scale` is ONE per-tensor factor
+// (scale_a * scale_b) applied in the epilogue.  First building block of BASELINE configs[4] (fp8 weights on CDNA4).
+// Geometry = the 256x128 ring kernel's: 8 waves of 64x64, three LDS stages of 3 x 16 KiB filled by LDS-DMA; a sub-tile row is
+// 128 BYTES = 128 k here (64 k in bf16), so one K-tile is one MFMA k-step: a wave's 16 MFMAs (32 cycles each) per 48 KiB
+// staged, the same matrix-pipe time per staged byte as bf16 at twice the FLOPs.  Operand k order inside an MFMA is free as
+// long as A and B agree (probed with exact integer data): lane (r = lane & 15, q = lane >> 4) takes bytes 32 q .. 32 q + 31 of
+// row r for both.  One barrier per K-tile; the next tile's fragment reads and the refill of the slot just consumed are issued
+// under the current tile's MFMAs (two register sets of fragments, loop unrolled by two).
+namespace fp8k {
+using bf16k::SUB; using bf16k::i32x4; using bf16k::dma16; using bf16k::make_rsrc;
+constexpr int BM = 256, BN = 128, BK = 128, STAGE_BYTES = 3 * SUB, LDS_BYTES = 3 * STAGE_BYTES;
+typedef __attribute__((ext_vector_type(8))) int i32x8;
+// wave-instruction `inst` (0..15) of a sub-tile [128 rows][128 bytes]: rows inst*8 + (lane>>3), 16-byte chunk (lane&7) ^ (row&7)
+__device__ __forceinline__ void stage_inst8(i32x4 rsrc, unsigned lds_sub, int ld, int X, int x0, int k0, int kend, int inst, int lane) {
+    const int r = inst * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ (r & 7);
+    const int gx = x0 + r, gk = k0 + 16 * c;
+    unsigned off = (unsigned)((size_t)gx * ld + gk);
+    if (gx >= X || gk >= kend) off = 0x80000000u;        // (K is a multiple of 16: a chunk is inside or outside as a whole)
+    dma16(rsrc, lds_sub + inst * 1024, off);
+}
+__device__ __forceinline__ i32x8 read_frag8(const char* S, int xb, int lane) {
+    const int row = xb + (lane & 15), c0 = 2 * (lane >> 4);
+    const i32x4 lo = *reinterpret_cast<const i32x4*>(S + row * 128 + (((c0) ^ (row & 7)) << 4));
+    const i32x4 hi = *reinterpret_cast<const i32x4*>(S + row * 128 + (((c0 + 1) ^ (row & 7)) << 4));
+    return (i32x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+__global__ __launch_bounds__(512, 2) void gemm_fp8(GemmParams p) {
+    __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    int tm, tn, z;
+    tile_of_block(p, BM, BN, blockIdx.x, gridDim.x, tm, tn, z);
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int nt = (p.K + BK - 1) / BK;
+    const i32x4 rA = make_rsrc(p.A), rB = make_rsrc(p.B);
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    auto stage = [&](int t, int slot) {
+        const unsigned S = lds0 + slot * STAGE_BYTES;
+        const int k0 = t * BK;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int g = wave * 4 + i;
+            stage_inst8(rA, S + (g >> 4) * SUB, p.lda, p.M, m0 + (g >> 4) * 128, k0, p.K, g & 15, lane);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) stage_inst8(rB, S + 2 * SUB, p.ldb, p.N, n0, k0, p.K, wave * 2 + i, lane);
+    };
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+        if (t < nt) stage(t, t);
+    if (nt >= 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if (nt == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    auto read_tile = [&](int slot, i32x8 (&fa)[4], i32x8 (&fb)[4]) {
+        const char* S = smem + slot * STAGE_BYTES;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fa[i] = read_frag8(S + (wm >> 1) * SUB, (wm & 1) * 64 + 16 * i, lane);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fb[j] = read_frag8(S + 2 * SUB, wn * 64 + 16 * j, lane);
+    };
+    // one K-tile: [tile t+1 has landed -> barrier -> refill the slot of tile t (everybody holds it in registers) -> issue the
+    // fragment reads of tile t+1 into the OTHER register set] under the 16 MFMAs of tile t -> the reads are complete
+    auto step = [&](int t, int slot, const i32x8 (&fa)[4], const i32x8 (&fb)[4], i32x8 (&na)[4], i32x8 (&nb)[4]) {
+        if (t + 1 < nt) {
+            // outstanding, oldest first: tile t+1, tile t+2 (6 pieces each)
+            if (t + 2 < nt) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (t + 3 < nt) stage(t + 3, slot);
+            read_tile(slot + 1 == 3 ? 0 : slot + 1, na, nb);
+        }
+        __builtin_amdgcn_s_setprio(1);
+        // operands swapped as in the bf16 kernels: D'[n][m], a lane owns 4 consecutive n of one row m
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fb[j], fa[i], acc[i][j], 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+        __builtin_amdgcn_s_setprio(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    i32x8 fa0[4], fb0[4], fa1[4], fb1[4];
+    if (nt > 0) read_tile(0, fa0, fb0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    int slot = 0;
+    for (int t = 0; t < nt; t += 2) {
+        step(t, slot, fa0, fb0, fa1, fb1);
+        slot = slot + 1 == 3 ? 0 : slot + 1;
+        if (t + 1 < nt) {
+            step(t + 1, slot, fa1, fb1, fa0, fb0);
+            slot = slot + 1 == 3 ? 0 : slot + 1;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    float lsum = 0.f;
+    bf16k::wave_epilogue<0, 0, 4, true>(p, acc, m0 + wm * 64, n0 + wn * 64, 0, reinterpret_cast<float*>(smem) + wave * 4096, lane, lsum);
+}
+}  // namespace fp8k
+hipError_t afr_launch_gemm_fp8(const GemmParams& p, hipStream_t s) {
+    if (p.M <= 0 || p.N <= 0) return hipSuccess;
+    if ((p.flags & (AFR_GEMM_A_KSTRIDED | AFR_GEMM_B_KSTRIDED)) || p.splitk != 1 || (p.K & 15) || (p.lda & 15) || (p.ldb & 15) ||
+        p.mse_target || p.ad_p || p.colsum || (p.flags & AFR_GEMM_RELU_MASK)) return hipErrorInvalidValue;
+    const int tiles = ((p.M + 255) / 256) * ((p.N + 127) / 128);
+    hipLaunchKernelGGL(fp8k::gemm_fp8, dim3(tiles), dim3(512), 0, s, p);
+    return hipGetLastError();
+}
 
 // ---------------------------------------------------------------------------------------- launch
 #ifdef AFR_GEMM_LAB

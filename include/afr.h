@@ -228,6 +228,17 @@ int afr_op_mse_grad(int act_dtype, const void* u, const void* target, int target
                     void* stream);
 int afr_op_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream);
 
+/* ---- fp8 building blocks of BASELINE configs[4] ("fp8 MFMA weights on CDNA4"; no counterpart in the reference) ----
+ * Operands are OCP e4m3fn bytes (gfx950's native fp8: exponent bias 7, largest finite 448, no infinities) with ONE float
+ * scale per tensor: value = scale * e4m3.  afr_op_f32_to_fp8: dst[i] = e4m3(src[i] / scale), round to nearest even,
+ * saturating.  afr_op_gemm_fp8: C[m][n] = scale_ab * sum_k A[m*lda+k] * B[n*ldb+k] (+bias[n]) (relu), f32 accumulation on
+ * the MX-scaled matrix instruction (v_mfma_scale_f32_16x16x128_f8f6f4, unit block scales: fp8 at twice the bf16 rate),
+ * C f32 or bf16 (AFR_GEMM_OUT_BF16); both operands k-contiguous (the forward form x . W^T), K, lda, ldb multiples of 16,
+ * N and ldc multiples of 8.  flags: AFR_GEMM_BIAS | AFR_GEMM_RELU | AFR_GEMM_OUT_BF16. */
+int afr_op_f32_to_fp8(const float* src, void* dst_e4m3, int64_t n, float scale, void* stream);
+int afr_op_gemm_fp8(int flags, const void* A, const void* B, void* C, const float* bias, int M, int N, int K, int lda, int ldb,
+                    int ldc, float scale_ab, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
