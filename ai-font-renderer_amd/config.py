@@ -89,6 +89,55 @@ class GlyphConfig:
         return out
 
 
+@dataclass(frozen=True)
+class PixelConfig:
+    """BASELINE.json configs[4] ("64x64 bitmap, 4-layer transformer (d_model=512, per-pixel tokens), fp8"): no class in the
+    reference.  Definition fixed in DESIGN.md 8: one token per output pixel, initialised from a learned
+    positional table (the reference's positional_encoding idiom, model.py:140-141); every block is pre-LayerNorm
+    cross-attention of the pixel tokens (queries) to the glyph's CONTEXT tokens [Emb[char], FontEmb[font]] (keys/values;
+    nn.MultiheadAttention with the packed in-projection of model.py:144) followed by a Linear-ReLU-Linear MLP (model.py:148
+    idiom), both residual; a final LayerNorm and a Linear d_model -> 1 per token give the pixel, clamped to [0,1]
+    (model.py:152-156).  Full self-attention over 4096 pixel tokens would cost 8x the FLOPs of everything else together."""
+    out_h: int = 64
+    out_w: int = 64
+    d_model: int = 512
+    heads: int = 8
+    layers: int = 4
+    ff_dim: int = 2048
+    vocab: int = 128
+    n_fonts: int = 2
+    ln_eps: float = 1e-5
+    kind: str = "pixel"
+
+    @property
+    def pixels(self):
+        return self.out_h * self.out_w
+
+    @property
+    def tokens(self):
+        return self.out_h * self.out_w
+
+    def param_shapes(self) -> List[Tuple[str, Tuple[int, ...]]]:
+        d, f = self.d_model, self.ff_dim
+        out = [("positional_encoding", (self.tokens, d)), ("embedding.weight", (self.vocab, d))]      # a module's own parameters come first
+        if self.n_fonts > 0:
+            out.append(("font_embedding.weight", (self.n_fonts, d)))
+        for l in range(self.layers):
+            q = f"layers.{l}."
+            out += [(q + "ln1.weight", (d,)), (q + "ln1.bias", (d,)),
+                    (q + "attn.in_proj_weight", (3 * d, d)), (q + "attn.in_proj_bias", (3 * d,)),
+                    (q + "attn.out_proj.weight", (d, d)), (q + "attn.out_proj.bias", (d,)),
+                    (q + "ln2.weight", (d,)), (q + "ln2.bias", (d,)),
+                    (q + "fc1.weight", (f, d)), (q + "fc1.bias", (f,)), (q + "fc2.weight", (d, f)), (q + "fc2.bias", (d,))]
+        out += [("ln_f.weight", (d,)), ("ln_f.bias", (d,)), ("fc_output.weight", (1, d)), ("fc_output.bias", (1,))]
+        return out
+
+    def train_flops_per_sample(self):
+        """3 x forward GEMM FLOPs: per token and layer q-proj + out-proj (2 d^2 each) and the MLP (4 d ff); the context side
+        (k/v projections of 2 tokens, 2-key attention) and the d -> 1 head are below 1 % and left out."""
+        return 3.0 * self.tokens * self.layers * (2.0 * 2 * self.d_model ** 2 + 4.0 * self.d_model * self.ff_dim)
+
+
 def flat_layout(cfg):
     """[(name, shape, offset, numel)], total: offsets in elements, each a multiple of ALIGN_ELEMS."""
     table, off = [], 0
@@ -108,3 +157,6 @@ WORKLOADS = {
     "c2": dict(cfg=GlyphConfig(hidden=(256,), out_h=16, out_w=16), batch=4096),
     "c3": dict(cfg=GlyphConfig(hidden=(1024, 1024), out_h=32, out_w=32, n_fonts=2), batch=8192),
 }
+# BASELINE configs[4] and the miniature the parity fixtures pin (tests/golden/pixel_twin.npz); no engine path yet: DESIGN.md 8
+C5 = PixelConfig()
+C5_MINI = PixelConfig(out_h=8, out_w=8)

@@ -142,15 +142,15 @@ def make_params(cfg, seed=SEED):
             a = hash_normal(tid, shape, 0.02, seed)                 # model.py:141
         elif name in ("embedding.weight", "font_embedding.weight"):
             a = hash_normal(tid, shape, 1.0, seed)                  # nn.Embedding default N(0,1)
-        elif name == "attention.in_proj_weight":
+        elif name.endswith("in_proj_weight"):
             a = hash_uniform(tid, shape, float(np.sqrt(6.0 / (shape[0] + shape[1]))), seed)
-        elif name == "layer_norm.weight":
+        elif name == "layer_norm.weight" or (len(shape) == 1 and name.split(".")[-2][:2] == "ln" and name.endswith(".weight")):
             a = 1.0 + hash_uniform(tid, shape, 0.1, seed)
-        elif name == "layer_norm.bias":
+        elif name == "layer_norm.bias" or (len(shape) == 1 and name.split(".")[-2][:2] == "ln" and name.endswith(".bias")):
             a = hash_uniform(tid, shape, 0.1, seed)
         elif name.endswith(".weight"):
             a = hash_uniform(tid, shape, float(1.0 / np.sqrt(shape[1])), seed)   # kaiming_uniform(a=sqrt5)
-        elif name == "attention.in_proj_bias" or name == "attention.out_proj.bias":
+        elif name.endswith("in_proj_bias") or name.endswith("out_proj.bias"):
             a = hash_uniform(tid, shape, 0.05, seed)
         else:  # Linear biases: U(+-1/sqrt(fan_in)); fan_in is the matching weight's 2nd dim
             wshape = dict(cfg.param_shapes())[name[:-4] + "weight"]

@@ -220,6 +220,125 @@ def glyph_backward(P, cache, du, cfg, rnd=None):
     return G
 
 
+# --------------------------------------------------------------------------- pixel-token transformer (C5)
+def _layernorm(x, g, b, eps):
+    mu = x.mean(-1, keepdim=True)
+    var = ((x - mu) ** 2).mean(-1, keepdim=True)                   # biased variance, as nn.LayerNorm
+    rstd = torch.rsqrt(var + eps)
+    xhat = (x - mu) * rstd
+    return xhat * g + b, xhat, rstd
+
+
+def _layernorm_bwd(dy, xhat, rstd, g):
+    """-> (dx, dgamma, dbeta): the LayerNorm backward of sheet_backward, for any leading shape."""
+    E = dy.shape[-1]
+    dg = (dy * xhat).reshape(-1, E).sum(0)
+    db = dy.reshape(-1, E).sum(0)
+    gg = dy * g
+    dx = (gg - gg.mean(-1, keepdim=True) - xhat * (gg * xhat).mean(-1, keepdim=True)) * rstd
+    return dx, dg, db
+
+
+def pixel_forward(P, x, font, cfg):
+    """BASELINE configs[4]'s model as DESIGN.md 8 defines it (config.PixelConfig): one token per output pixel; 4 pre-LayerNorm
+    blocks of cross-attention (pixel queries -> the glyph's context tokens [Emb[char], FontEmb[font]]) and a
+    Linear-ReLU-Linear MLP, both residual; LayerNorm + Linear d -> 1 per token; clamp.  The reference has no such class:
+    every piece is one of its layer idioms -- Embedding gather model.py:136,167; learned positional table :140-141,171-172;
+    nn.MultiheadAttention packed in-projection, q * sqrt(1/D), softmax, out-proj :144,175-177; LayerNorm :145,180; Linear +
+    ReLU :148,183; Linear + clamp :152-156,196-202.  PARITY: unpinned by the reference; pinned to a torch.nn composition
+    of exactly these modules (tests/golden/pixel_twin.npz, made by make_golden.py pixel_twin)."""
+    B = x.shape[0]
+    d, H, T = cfg.d_model, cfg.heads, cfg.tokens
+    D = d // H
+    ctx = P["embedding.weight"][x].unsqueeze(1)                                   # [B, 1, d]
+    if cfg.n_fonts > 0:
+        ctx = torch.cat([ctx, P["font_embedding.weight"][font].unsqueeze(1)], 1)  # [B, C, d]
+    C = ctx.shape[1]
+    h = P["positional_encoding"].unsqueeze(0).expand(B, T, d)
+    scale = math.sqrt(1.0 / D)
+    saved = []
+    for l in range(cfg.layers):
+        q_ = f"layers.{l}."
+        Win, bin_ = P[q_ + "attn.in_proj_weight"], P[q_ + "attn.in_proj_bias"]
+        n1, xh1, rs1 = _layernorm(h, P[q_ + "ln1.weight"], P[q_ + "ln1.bias"], cfg.ln_eps)
+        q = n1 @ Win[:d].t() + bin_[:d]                                           # [B, T, d]
+        k = ctx @ Win[d:2 * d].t() + bin_[d:2 * d]                                # [B, C, d]
+        v = ctx @ Win[2 * d:].t() + bin_[2 * d:]
+        qh = q.reshape(B, T, H, D).permute(0, 2, 1, 3)                            # [B, H, T, D]
+        kh = k.reshape(B, C, H, D).permute(0, 2, 1, 3)
+        vh = v.reshape(B, C, H, D).permute(0, 2, 1, 3)
+        A = torch.softmax((qh * scale) @ kh.transpose(-1, -2), dim=-1)            # [B, H, T, C]
+        o = (A @ vh).permute(0, 2, 1, 3).reshape(B, T, d)
+        h1 = h + o @ P[q_ + "attn.out_proj.weight"].t() + P[q_ + "attn.out_proj.bias"]
+        n2, xh2, rs2 = _layernorm(h1, P[q_ + "ln2.weight"], P[q_ + "ln2.bias"], cfg.ln_eps)
+        pre = n2 @ P[q_ + "fc1.weight"].t() + P[q_ + "fc1.bias"]
+        f = torch.relu(pre)
+        h2 = h1 + f @ P[q_ + "fc2.weight"].t() + P[q_ + "fc2.bias"]
+        saved.append(dict(n1=n1, xh1=xh1, rs1=rs1, qh=qh, kh=kh, vh=vh, A=A, o=o, n2=n2, xh2=xh2, rs2=rs2, pre=pre, f=f))
+        h = h2
+    nf, xhf, rsf = _layernorm(h, P["ln_f.weight"], P["ln_f.bias"], cfg.ln_eps)
+    u = (nf @ P["fc_output.weight"].t() + P["fc_output.bias"]).squeeze(-1)        # [B, T]
+    y = u.clamp(0.0, 1.0).reshape(B, cfg.out_h, cfg.out_w)
+    return y, dict(x=x, font=font, ctx=ctx, saved=saved, nf=nf, xhf=xhf, rsf=rsf, u=u)
+
+
+def pixel_backward(P, cache, du, cfg):
+    """Reverse of pixel_forward (what loss.backward() does on the torch.nn twin); du [B, T]: gradient w.r.t. the pre-clamp
+    output (clamp mask applied).  Returns the gradients of every parameter."""
+    B = du.shape[0]
+    d, H, T = cfg.d_model, cfg.heads, cfg.tokens
+    D = d // H
+    ctx = cache["ctx"]
+    C = ctx.shape[1]
+    scale = math.sqrt(1.0 / D)
+    G = {}
+    G["fc_output.weight"] = (du.reshape(-1, 1) * cache["nf"].reshape(-1, d)).sum(0, keepdim=True)
+    G["fc_output.bias"] = du.sum().reshape(1)
+    dnf = du.unsqueeze(-1) * P["fc_output.weight"].reshape(1, 1, d)
+    dh, G["ln_f.weight"], G["ln_f.bias"] = _layernorm_bwd(dnf, cache["xhf"], cache["rsf"], P["ln_f.weight"])
+    dctx = torch.zeros_like(ctx)
+    for l in reversed(range(cfg.layers)):
+        q_ = f"layers.{l}."
+        c = cache["saved"][l]
+        Win = P[q_ + "attn.in_proj_weight"]
+        # MLP:  h2 = h1 + fc2(relu(fc1(LN2(h1))))
+        G[q_ + "fc2.weight"] = dh.reshape(-1, d).t() @ c["f"].reshape(-1, cfg.ff_dim)
+        G[q_ + "fc2.bias"] = dh.reshape(-1, d).sum(0)
+        dpre = (dh @ P[q_ + "fc2.weight"]) * (c["pre"] > 0).to(dh.dtype)
+        G[q_ + "fc1.weight"] = dpre.reshape(-1, cfg.ff_dim).t() @ c["n2"].reshape(-1, d)
+        G[q_ + "fc1.bias"] = dpre.reshape(-1, cfg.ff_dim).sum(0)
+        dx2, G[q_ + "ln2.weight"], G[q_ + "ln2.bias"] = _layernorm_bwd(dpre @ P[q_ + "fc1.weight"], c["xh2"], c["rs2"], P[q_ + "ln2.weight"])
+        dh1 = dh + dx2
+        # attention:  h1 = h + out_proj(softmax(q k^T) v)
+        G[q_ + "attn.out_proj.weight"] = dh1.reshape(-1, d).t() @ c["o"].reshape(-1, d)
+        G[q_ + "attn.out_proj.bias"] = dh1.reshape(-1, d).sum(0)
+        do = (dh1 @ P[q_ + "attn.out_proj.weight"]).reshape(B, T, H, D).permute(0, 2, 1, 3)      # [B, H, T, D]
+        dA = do @ c["vh"].transpose(-1, -2)                                                      # [B, H, T, C]
+        dv = c["A"].transpose(-1, -2) @ do                                                       # [B, H, C, D]
+        dS = c["A"] * (dA - (dA * c["A"]).sum(-1, keepdim=True))
+        dq = (dS @ c["kh"]) * scale
+        dk = dS.transpose(-1, -2) @ (c["qh"] * scale)
+        dq_ = dq.permute(0, 2, 1, 3).reshape(B, T, d)
+        dk_ = dk.permute(0, 2, 1, 3).reshape(B, C, d)
+        dv_ = dv.permute(0, 2, 1, 3).reshape(B, C, d)
+        gw = torch.cat([dq_.reshape(-1, d).t() @ c["n1"].reshape(-1, d), dk_.reshape(-1, d).t() @ ctx.reshape(-1, d),
+                        dv_.reshape(-1, d).t() @ ctx.reshape(-1, d)], 0)
+        G[q_ + "attn.in_proj_weight"] = gw
+        G[q_ + "attn.in_proj_bias"] = torch.cat([dq_.reshape(-1, d).sum(0), dk_.reshape(-1, d).sum(0), dv_.reshape(-1, d).sum(0)])
+        dctx = dctx + dk_ @ Win[d:2 * d] + dv_ @ Win[2 * d:]
+        dx1, G[q_ + "ln1.weight"], G[q_ + "ln1.bias"] = _layernorm_bwd(dq_ @ Win[:d], c["xh1"], c["rs1"], P[q_ + "ln1.weight"])
+        dh = dh1 + dx1
+    G["positional_encoding"] = dh.sum(0)
+    dEmb = torch.zeros_like(P["embedding.weight"])
+    dEmb.index_add_(0, cache["x"], dctx[:, 0])
+    G["embedding.weight"] = dEmb
+    if cfg.n_fonts > 0:
+        dF = torch.zeros_like(P["font_embedding.weight"])
+        dF.index_add_(0, cache["font"], dctx[:, 1])
+        G["font_embedding.weight"] = dF
+    return G
+
+
 # --------------------------------------------------------------------------- loss / optimiser
 def mse_loss_grad(u, target, total_elems=None, clamp_mask=None):
     """F.mse_loss(clamp(u,0,1), target) and its gradient w.r.t. u (model.py:156,268-270).
@@ -272,6 +391,10 @@ def train_step(P, M, V, t, x, target, cfg, font=None, masks=None, lr=1e-3, beta1
         _, cache = sheet_forward(P, x, cfg, masks)
         loss, du = mse_loss_grad(cache["u"], target)
         G = sheet_backward(P, cache, du, cfg)
+    elif cfg.kind == "pixel":
+        _, cache = pixel_forward(P, x, font, cfg)
+        loss, du = mse_loss_grad(cache["u"], target)
+        G = pixel_backward(P, cache, du, cfg)
     else:
         _, cache = glyph_forward(P, x, font, cfg)
         loss, du = mse_loss_grad(cache["u"], target)

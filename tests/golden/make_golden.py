@@ -311,6 +311,98 @@ def glyph_twin():
     print("glyph_twin.npz", {k: fx[k].shape for k in list(fx)[:6]})
 
 
+class PixelTwin(torch.nn.Module):
+    """torch.nn composition of config.PixelConfig (BASELINE configs[4] as DESIGN.md 8 defines it) from the reference's layer
+    idioms: nn.Embedding (model.py:136), a learned positional nn.Parameter (:140-141), nn.MultiheadAttention (:144), nn.LayerNorm
+    (:145), nn.Linear + relu (:148,183), nn.Linear + clamp (:152-156).  The reference itself has no such class."""
+
+    class Block(torch.nn.Module):
+        def __init__(self, d, heads, ff, eps):
+            super().__init__()
+            self.ln1 = torch.nn.LayerNorm(d, eps=eps)
+            self.attn = torch.nn.MultiheadAttention(embed_dim=d, num_heads=heads, batch_first=True)
+            self.ln2 = torch.nn.LayerNorm(d, eps=eps)
+            self.fc1 = torch.nn.Linear(d, ff)
+            self.fc2 = torch.nn.Linear(ff, d)
+
+    def __init__(self, cfg):
+        super().__init__()
+        self.cfg = cfg
+        d = cfg.d_model
+        self.embedding = torch.nn.Embedding(cfg.vocab, d)
+        if cfg.n_fonts > 0:
+            self.font_embedding = torch.nn.Embedding(cfg.n_fonts, d)
+        self.positional_encoding = torch.nn.Parameter(torch.zeros(cfg.tokens, d))
+        self.layers = torch.nn.ModuleList([PixelTwin.Block(d, cfg.heads, cfg.ff_dim, cfg.ln_eps) for _ in range(cfg.layers)])
+        self.ln_f = torch.nn.LayerNorm(d, eps=cfg.ln_eps)
+        self.fc_output = torch.nn.Linear(d, 1)
+
+    def forward(self, x, font=None):
+        B = x.shape[0]
+        ctx = self.embedding(x).unsqueeze(1)
+        if self.cfg.n_fonts > 0:
+            ctx = torch.cat([ctx, self.font_embedding(font).unsqueeze(1)], 1)
+        h = self.positional_encoding.unsqueeze(0).expand(B, -1, -1)
+        for blk in self.layers:
+            a, _ = blk.attn(blk.ln1(h), ctx, ctx)                     # (out, weights) as the reference calls it, model.py:176
+            h = h + a
+            h = h + blk.fc2(F.relu(blk.fc1(blk.ln2(h))))
+        u = self.fc_output(self.ln_f(h)).squeeze(-1)
+        return torch.clamp(u, 0, 1).view(B, self.cfg.out_h, self.cfg.out_w)
+
+
+def _summary(fx, key, a, idx_seed):
+    """Full tensor when small, else row sums, column sums and 2048 hashed samples (as sheet_r0's fc_output.weight.grad)."""
+    a = np.asarray(a)
+    if a.size <= 70000:
+        fx[key] = a
+        return
+    a2 = a.reshape(a.shape[0], -1)
+    idx = (synth._counter(idx_seed, 2048, 42) % np.uint64(a.size)).astype(np.int64)
+    fx[key + "/rowsum"], fx[key + "/colsum"], fx[key + "/idx"], fx[key + "/samples"] = a2.sum(1), a2.sum(0), idx, a.reshape(-1)[idx]
+
+
+def pixel_twin():
+    """C5-mini (8x8 = 64 pixel tokens, d_model 512, 8 heads, 4 layers, ff 2048, batch 32): eval bitmaps, loss, every gradient
+    and a 3-step AdamW trajectory of the torch.nn twin -- what oracle.pixel_forward / pixel_backward are pinned to."""
+    from ai_font_renderer_amd.config import C5_MINI as cfg
+    B = 32
+    i = np.arange(B)
+    x = (32 + (i * 7) % 95).astype(np.int64)
+    font = ((i // 3) % cfg.n_fonts).astype(np.int64)
+    tu8 = synth.hash_u8(960, (B, cfg.out_h, cfg.out_w))
+    xt, ft, tgt = torch.from_numpy(x), torch.from_numpy(font), torch.from_numpy(tu8.astype(np.float32) / 255.0)
+    tw = PixelTwin(cfg)
+    tw.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_params(cfg).items()})
+    assert [k for k, _ in tw.named_parameters()] == [k for k, _ in cfg.param_shapes()]     # state_dict order == the config's
+    fx = dict(x=x, font=font, target_u8=tu8)
+    tw.eval()
+    with torch.no_grad():
+        fx["eval_y"] = tw(xt, ft).numpy()
+    tw.train()
+    # (the reference's rate, 1e-3, saturates this 12.7 M-parameter net's clamp in ONE step -- loss 0.283 -> 0.3348 and constant
+    # from then on, a dead trajectory that pins nothing; at 1e-4 the loss still rises; 1e-5 descends: 0.283 -> 0.266 -> 0.242)
+    lr = 0.01 * ref.LEARNING_RATE
+    fx["lr"] = np.float64(lr)
+    opt = torch.optim.AdamW(tw.parameters(), lr=lr, weight_decay=ref.WEIGHT_DECAY, betas=(0.9, 0.99))
+    losses = []
+    for step in range(3):
+        opt.zero_grad()
+        loss = F.mse_loss(tw(xt, ft), tgt)
+        loss.backward()
+        if step == 0:
+            for n_, (k, p) in enumerate(tw.named_parameters()):
+                _summary(fx, "grad/" + k, p.grad.detach().numpy(), 7000 + n_)
+        opt.step()
+        losses.append(loss.item())
+    fx["losses"] = np.array(losses, dtype=np.float32)
+    for n_, (k, p) in enumerate(tw.named_parameters()):
+        _summary(fx, "param3/" + k, p.detach().numpy(), 7000 + n_)
+    assert len(set(losses)) == 3 and losses[2] < losses[0], losses
+    np.savez_compressed(os.path.join(OUT, "pixel_twin.npz"), **fx)
+    print("pixel_twin.npz losses", losses, "clamped-inside fraction", float(((fx["eval_y"] > 0) & (fx["eval_y"] < 1)).mean()))
+
+
 def glyph_bitmaps():
     from ai_font_renderer_amd import datagen
     fonts = ["/root/reference/FiraCode-Retina.ttf", "/root/reference/Montserrat-Regular.ttf"]
@@ -524,7 +616,7 @@ def helpers_fx():
 
 if __name__ == "__main__":
     only = sys.argv[1:]
-    for fn in (glyph_ref1, glyph_twin, glyph_bitmaps, train_loop, mini, helpers_fx, r0):
+    for fn in (glyph_ref1, glyph_twin, pixel_twin, glyph_bitmaps, train_loop, mini, helpers_fx, r0):
         if not only or fn.__name__ in only:
             fn()
     if "cpu_step_times" in only:              # timing, not a parity fixture: only on request
