@@ -89,3 +89,34 @@ def test_fp8_gemm_rate_against_the_5pf_roof():
     pf = 2.0 * M * N * K / (ms * 1e-3) / 1e15
     print(f"fp8 gemm 8192^3: {ms * 1e3:.1f} us, {pf:.2f} PF = {pf / 5.0:.2f} of the 5 PF dense fp8 peak")
     assert pf > 1.3
+
+
+def test_fp8_linear_on_the_c5_mini_layer_shapes():
+    """BASELINE configs[4] in miniature: the first block's MLP up-projection of the C5-mini fixture model (pixel_twin.npz's
+    net: 32 glyphs x 64 pixel tokens = 2048 rows, d_model 512 -> ff 2048) with fp8 weights AND activations through
+    afr_op_gemm_fp8 (bias + ReLU epilogue, bf16 out).  Against the exact product of the e4m3 operands (kernel correctness)
+    and against the f32 oracle's relu(fc1(LN2(h))) (what e4m3 costs on this layer: a few percent of the largest activation)."""
+    from ai_font_renderer_amd.config import C5_MINI as cfg
+    from .util import load, oracle, tparams
+    lib = _lib.lib()
+    fx = load("pixel_twin.npz")
+    P = tparams(cfg)
+    _, cache = oracle.pixel_forward(P, torch.from_numpy(fx["x"]), torch.from_numpy(fx["font"]), cfg)
+    n2 = cache["saved"][0]["n2"].reshape(-1, cfg.d_model)             # [2048, 512]
+    W, b = P["layers.0.fc1.weight"], P["layers.0.fc1.bias"]
+    f_ref = cache["saved"][0]["f"].reshape(-1, cfg.ff_dim)
+    sa, sw = float(n2.abs().max()) / 448.0, float(W.abs().max()) / 448.0
+    A8, Av = _to_fp8(n2, sa)
+    W8, Wv = _to_fp8(W, sw)
+    M, K, N = n2.shape[0], cfg.d_model, cfg.ff_dim
+    out = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device="cuda")
+    _lib.check(lib.afr_op_gemm_fp8(_lib.GEMM_BIAS | _lib.GEMM_RELU | _lib.GEMM_OUT_BF16, ptr(A8), ptr(W8), ptr(out), ptr(dev(b)), M, N, K, K, K, N,
+                                   sa * sw, stream()))
+    torch.cuda.synchronize()
+    got = out.float().cpu().double()
+    exact = torch.relu(Av.double() @ Wv.double().t() + b.double())
+    top = float(f_ref.abs().max())
+    assert float((got - exact).abs().max()) < 1e-2 * top                       # bf16 output rounding
+    err = float((got - f_ref.double()).abs().max()) / top
+    print(f"C5-mini fc1 in e4m3 (per-tensor scales): max |err| = {err:.3f} of the largest activation")
+    assert err < 8e-2
