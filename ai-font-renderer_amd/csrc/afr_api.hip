@@ -87,6 +87,9 @@ struct afr_plan {
     // glyph, bf16 training steps: the first layer's output as a COMBINATION table (elementwise.hip glyph_combo_kernel): h1 / h0
     // are not materialised per glyph; the products that consume them gather table rows through cidx while staging
     bool combo_ok = false, combo_on = false; size_t o_h1c = 0, o_h0c = 0, o_cidx = 0; int h1c_ld = 0;
+    // glyph, bf16 training steps: hidden activations written by a GEMM epilogue also leave their ReLU mask as bits
+    // (o_mbits[i] for the output of layer i, 0 = none); the next layer's input-gradient product reads those instead of the activation
+    std::vector<size_t> o_mbits; bool mbits_on = false;
     size_t o_fix = 0, o_fixcnt = 0; bool have_fix = false;   // in-launch split-K: slice parking area + per-tile arrival counters
     // bf16 glyph nets: TWO weight shadows.  A fused optimizer step writes every tensor's new bf16 copy into the one that is
     // not being read (a layer's weight-gradient workgroups update the weights while the same launch's input-gradient
@@ -249,6 +252,10 @@ extern "C" int afr_plan_create(const afr_config* c, afr_plan** out) {
             p->o_act.push_back(carve(B * (size_t)c->hidden[i] * ab));
             if ((size_t)c->hidden[i] > maxw) maxw = (size_t)c->hidden[i];
         }
+        p->o_mbits.assign(c->n_hidden + 1, 0);
+        if (c->dtype == AFR_BF16 && !(c->reserved & 128))
+            for (int i = 1; i < c->n_hidden; ++i)          // layer 0's output comes from the table / gather kernels, not a GEMM
+                if (c->hidden[i] % 8 == 0) p->o_mbits[i] = carve(B * (size_t)(c->hidden[i] / 8));
         p->o_u = carve(B * Pix * ab);
         p->o_d[0] = carve(B * maxw * ab);
         p->o_d[1] = carve(B * maxw * ab);
@@ -500,7 +507,8 @@ extern "C" int afr_profile_dump(afr_plan* p, char* buf, int cap) {
 struct FusedLoss { const void* target; int tdtype; int64_t mean_elems; float* loss_accum; };
 struct FusedAdam { float *p, *m, *v; bf16_t* shadow; float decay, b1, b2, eps, step_size, rsqrt_bc2; };
 struct CoopArgs { float* ws; unsigned* cnt; unsigned target; };
-struct RowMaps { const int* a; const int* b; const int* aux; };     // GemmParams::a_rowmap / b_rowmap / aux_rowmap
+struct RowMaps { const int* a; const int* b; const int* aux;        // GemmParams::a_rowmap / b_rowmap / aux_rowmap
+                 unsigned char* mask_out = nullptr; const unsigned char* mask_in = nullptr; int ldmask = 0; };   // ... mask_out / mask_in
 // the bf16 weight shadow the GEMMs read / the one a fused optimizer step writes (the same buffer unless the plan has two)
 static inline bf16_t* shadow_rd(const afr_plan* p) {
     if (p->cfg.dtype != AFR_BF16) return nullptr;
@@ -530,7 +538,7 @@ static int run_gemm(afr_plan* p, hipStream_t s, int flags, const void* A, const 
         g.ad_decay = fa->decay; g.ad_b1 = fa->b1; g.ad_b2 = fa->b2; g.ad_eps = fa->eps; g.ad_step = fa->step_size; g.ad_rsqrt_bc2 = fa->rsqrt_bc2;
     }
     g.colsum = colsum; g.colsum_stride = colsum_stride;
-    if (rm) { g.a_rowmap = rm->a; g.b_rowmap = rm->b; g.aux_rowmap = rm->aux; }
+    if (rm) { g.a_rowmap = rm->a; g.b_rowmap = rm->b; g.aux_rowmap = rm->aux; g.mask_out = rm->mask_out; g.mask_in = rm->mask_in; g.ldmask = rm->ldmask; }
     if (coop) { g.coop_ws = coop->ws; g.coop_cnt = coop->cnt; g.coop_target = coop->target; g.err = (uint32_t*)(p->ws + p->o_err); }
     if (fl) {
         float* scratch = (float*)(p->ws + p->o_loss);
@@ -748,13 +756,16 @@ static int forward_impl(afr_plan* p, const int64_t* x, const int64_t* font, int 
             ProfScope ps(p, s, "glyph_embed", 0.0, 0.0);
             HIPCHK(afr_launch_glyph_embed(c.dtype, p->P + p->emb_off, femb, x, font, B, c.embed_dim, c.vocab, c.n_fonts, h, err, s));
         }
+        const bool bits = fl != nullptr && c.dtype == AFR_BF16;
         for (int i = first; i < nl; ++i) {
             const auto& l = p->layers[i];
             const bool last = (i == nl - 1);
             void* outp = last ? u : (void*)(p->ws + p->o_act[i + 1]);
+            RowMaps rmi{(combo && i == 1) ? rma.a : nullptr, nullptr, nullptr};
+            if (bits && !last && p->o_mbits[i]) { rmi.mask_out = (unsigned char*)(p->ws + p->o_mbits[i]); rmi.ldmask = l.N / 8; }
             int rc = run_gemm(p, s, AFR_GEMM_BIAS | (last ? 0 : AFR_GEMM_RELU) | ob, h, weight_ptr(p, l.w_off), outp,
                               p->P + l.b_off, nullptr, B, l.N, l.K, (combo && i == 1) ? p->h1c_ld : l.K, l.K, l.N, 0, 1, 0, nullptr, 0,
-                              last ? fl : nullptr, nullptr, nullptr, (combo && i == 1) ? &rma : nullptr);
+                              last ? fl : nullptr, nullptr, nullptr, (rmi.a || rmi.mask_out) ? &rmi : nullptr);
             if (rc) return rc;
             h = outp;
         }
@@ -767,6 +778,7 @@ static int forward_impl(afr_plan* p, const int64_t* x, const int64_t* font, int 
     p->last_x = x; p->last_font = font; p->last_B = B; p->last_training = training; p->last_step = step;
     p->next_stage = 0;
     p->combo_on = c.kind == AFR_KIND_GLYPH && fl != nullptr && p->k0 && combo_for(p, B);
+    p->mbits_on = c.kind == AFR_KIND_GLYPH && fl != nullptr && c.dtype == AFR_BF16;
     p->have_du = fl != nullptr;      // with the loss fused into the last layer's epilogue the buffer already holds du
     return AFR_OK;
 }
@@ -930,9 +942,11 @@ static int backward_stage_impl(afr_plan* p, int stage, int64_t* g_off, int64_t* 
     if ((rc = run_dw(p, s, l, dy, a, B, rt, sk_group, coop, cidx, p->h1c_ld))) { p->defer = false; p->pend.clear(); p->pend_tag.clear(); p->pend_flops = p->pend_bytes = 0.0; return rc; }
     void* dx = p->ws + p->o_d[stage & 1];
     const int fl = AFR_GEMM_B_KSTRIDED | ob | (i > 0 ? AFR_GEMM_RELU_MASK : 0);
-    const RowMaps rmx{nullptr, nullptr, cidx};
+    RowMaps rmx{nullptr, nullptr, cidx};
+    const bool use_bits = p->mbits_on && i >= 2 && p->o_mbits[i - 1] && (fl & AFR_GEMM_OUT_BF16);
+    if (use_bits) { rmx.mask_in = (const unsigned char*)(p->ws + p->o_mbits[i - 1]); rmx.ldmask = l.K / 8; }
     if ((rc = run_gemm(p, s, fl, dy, weight_ptr(p, l.w_off), dx, nullptr, i > 0 ? a : nullptr, B, l.K, l.N, l.N, l.K, l.K,
-                       gath ? p->h1c_ld : l.K, 1, 0, nullptr, 0, nullptr, nullptr, nullptr, gath ? &rmx : nullptr))) { p->defer = false; p->pend.clear(); p->pend_tag.clear(); p->pend_flops = p->pend_bytes = 0.0; return rc; }
+                       gath ? p->h1c_ld : l.K, 1, 0, nullptr, 0, nullptr, nullptr, nullptr, (gath || use_bits) ? &rmx : nullptr))) { p->defer = false; p->pend.clear(); p->pend_tag.clear(); p->pend_flops = p->pend_bytes = 0.0; return rc; }
     if ((rc = flush_gemms(p, s))) return rc;
     const int64_t end = l.b_off + (l.N + 63) / 64 * 64;
     if (i > 0) {

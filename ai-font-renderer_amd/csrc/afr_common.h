@@ -131,6 +131,10 @@ struct GemmParams {
     // 256x256 kernel, aux with a bf16 output; the launchers refuse anything else.
     const int* a_rowmap = nullptr; const int* b_rowmap = nullptr; const int* aux_rowmap = nullptr;
     float out_scale = 1.f;     // fp8 products: scale_a * scale_b, applied to the accumulators ahead of bias / ReLU
+    // optional ReLU mask as BITS (bf16 output only; N a multiple of 8): a forward layer with AFR_GEMM_RELU leaves bit (n & 7)
+    // of mask_out[m * ldmask + n / 8] = [stored activation (m, n) > 0]; an input-gradient product with AFR_GEMM_RELU_MASK
+    // reads mask_in in that layout INSTEAD of the activation aux (1/16 of its bytes: C3's 16.8 MB mask read becomes 1 MB)
+    unsigned char* mask_out = nullptr; const unsigned char* mask_in = nullptr; int ldmask = 0;
 #ifdef AFR_GEMM_TIMING
     int dbg_slot = 0;     // kernel-development builds: which 1024-block region of the stamp buffer this launch writes
 #endif

@@ -67,7 +67,11 @@ typedef struct afr_config {
                             instead of the fused kernel (A/B measurements, parity cross-checks)
                             bit 5: weight gradients of grouped 256x256 launches as split-K partial slabs summed by the grouped
                             reduce, instead of the cooperative split-K whose slices meet inside the launch (A/B measurements,
-                            parity cross-checks: the two give bitwise equal results)                                    */
+                            parity cross-checks: the two give bitwise equal results)
+                            bit 6: the glyph nets' first layer through the gather kernel + dense h1 in training steps too,
+                            instead of the (character, font) combination table gathered inside the consuming products
+                            bit 7: ReLU masks of the input-gradient products read from the stored activations instead of the
+                            bit masks the forward epilogues leave (bits 6, 7: A/B measurements; bitwise equal results)      */
 } afr_config;
 
 typedef struct afr_plan afr_plan;
