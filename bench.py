@@ -132,7 +132,9 @@ def pmc_traffic(workload, kernel):
     path = os.path.join(ROOT, rel)
     if not os.path.exists(path):
         return None, f"no PMC passes committed for {PROFILE_ROUND} yet"
-    table = json.load(open(path)).get(workload, {})
+    table = json.load(open(path)).get(workload)
+    if table is None:
+        return None, f"{rel} holds no PMC passes of workload {workload}"          # (collected for c3 and r0 only)
     stem = kernel[:-1] if kernel.endswith(">") else kernel
     hits = [k for k in table if k == kernel or (kernel.endswith(">") and k.startswith(stem) and k[len(stem):len(stem) + 1] in (",", ">"))]
     if len(hits) != 1:

@@ -1,12 +1,12 @@
 #!/bin/bash
 # Collect the per-round profile evidence on the GPU box (run through gpurun from the repo root):
-#   tools/collect_profiles.sh <round, e.g. r02>
+#   tools/collect_profiles.sh <round, e.g. r03>
 # 1. bench logs (c1, c2, c3, r0)                         -> gpurun_out/<round>/bench_*.log
 # 2. rocprofv3 --kernel-trace --stats of bench.py        -> gpurun_out/<round>/stats_{c3,r0}/
 # 3. PMC passes, each in its own run with no trace flags -> gpurun_out/<round>/pmc_{c3,r0}_{FETCH_SIZE,WRITE_SIZE,MFMA}/
 # The program follows `--` directly (python3 bench.py ...): no env / shell wrapper between rocprofv3 and it.
 set -e
-R=${1:-r02}
+R=${1:-r03}
 O=gpurun_out/$R
 mkdir -p $O
 export TMPDIR=/tmp
@@ -17,6 +17,10 @@ for w in c1 c2 c3 r0; do
 done
 python3 bench.py --steps 200 --warmup 20 > $O/bench_default.log 2>&1
 echo "bench default done"
+for w in c1 c2; do       # the latency-bound small nets: kernel statistics only
+  rocprofv3 --kernel-trace --stats -d $O/stats_$w -o $w -- python3 bench.py --workload $w $B > $O/stats_$w.log 2>&1
+  echo "stats $w done"
+done
 for w in c3 r0; do
   rocprofv3 --kernel-trace --stats -d $O/stats_$w -o $w -- python3 bench.py --workload $w $B > $O/stats_$w.log 2>&1
   echo "stats $w done"
@@ -29,5 +33,5 @@ for w in c3 r0; do
 done
 python3 tools/pmc_summary.py $O/pmc c3 r0 --json $O/pmc_traffic.json > $O/pmc_hbm_traffic.txt
 python3 tools/pmc_mfma_summary.py $O/pmc c3 r0 > $O/pmc_mfma_busy.txt
-for w in c3 r0; do python3 tools/pmc_summary.py --stats $O/stats_$w > $O/${w}_kernel_stats.csv; done
+for w in c1 c2 c3 r0; do python3 tools/pmc_summary.py --stats $O/stats_$w > $O/${w}_kernel_stats.csv; done
 echo "profiles collected under $O"
