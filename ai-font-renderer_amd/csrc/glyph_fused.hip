@@ -37,7 +37,7 @@ template <> struct MM<float> {
     }
 };
 template <> struct MM<bf16_t> {
-    static constexpr int KB = 32, R = 32, NTH = 512;
+    static constexpr int KB = 32, R = 64, NTH = 512;
     static __device__ __forceinline__ void mma(f32x4& acc, const i32x4 a, const i32x4 b) {
         acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
     }
