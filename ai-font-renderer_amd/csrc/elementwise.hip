@@ -541,15 +541,22 @@ hipError_t afr_launch_glyph_l1_fwd(int act_dtype, const float* emb, const float*
 // (0.5 MB + 16 KB + 32 KB, L2-resident); the GEMM kernels that consume h1 / h0 gather their operand rows through cidx while
 // staging (GemmParams::a_rowmap / b_rowmap / aux_rowmap; LDS-DMA takes a per-lane source address, so a gathered row costs
 // what a dense one does).  Same values bit for bit as the gather kernel's h1 / h0, same FLOPs in every product.
-__global__ __launch_bounds__(256) void glyph_combo_kernel(const float* __restrict__ table, const float* __restrict__ b1,
+// One kernel: a block takes CB_COMBOS combinations x 256 fc1 rows (grid x: combination groups, then the batch's index
+// blocks; grid y: 256-row chunks of fc1), stages its W1 rows through LDS as glyph_table_kernel does and runs the SAME
+// arithmetic as the table + gather kernels, in the same order: t_c = fma chain over k from 0 of Emb[x][k] W1[n][k], t_f likewise
+// for the font row, v = (t_c + b1[n]) + t_f, ReLU, one rounding to bf16 -- bit for bit the dense path's h1.
+constexpr int CB_COMBOS = 4;
+__global__ __launch_bounds__(256) void glyph_combo_kernel(const float* __restrict__ W1, const float* __restrict__ b1,
                                                           const float* __restrict__ emb, const float* __restrict__ femb,
                                                           const int64_t* __restrict__ x, const int64_t* __restrict__ font,
-                                                          int B, int E, int N1, int vocab, int n_fonts, int tab_blocks,
+                                                          int B, int E, int N1, int vocab, int n_fonts, int combo_blocks,
                                                           bf16_t* __restrict__ h1c, int ld1, bf16_t* __restrict__ h0c, int* __restrict__ cidx,
-                                                          uint32_t* err_flag) {
-    const int nf = max(n_fonts, 1);
-    if ((int)blockIdx.x >= tab_blocks) {                  // the batch's combination indices (with the index check of the gather)
-        const int b = ((int)blockIdx.x - tab_blocks) * 256 + threadIdx.x;
+                                                          bf16_t* __restrict__ w1t, uint32_t* err_flag) {
+    extern __shared__ float sm[];                         // W [256][E+1] | emb rows [CB][E] | font rows [CB][E]
+    const int nf = max(n_fonts, 1), ncombo = vocab * nf;
+    if ((int)blockIdx.x >= combo_blocks) {                // the batch's combination indices (with the index check of the gather)
+        if (blockIdx.y != 0) return;
+        const int b = ((int)blockIdx.x - combo_blocks) * 256 + threadIdx.x;
         if (b >= B) return;
         long long xi = x[b], fi = (n_fonts > 0 && font) ? font[b] : 0;
         if (xi < 0 || xi >= vocab) { atomicOr(err_flag, 1u); xi = min(max(xi, 0ll), (long long)vocab - 1); }
@@ -557,44 +564,60 @@ __global__ __launch_bounds__(256) void glyph_combo_kernel(const float* __restric
         cidx[b] = (int)(xi * nf + fi);
         return;
     }
-    const int c = blockIdx.x, xi = c / nf, fi = c - xi * nf;
-    const float* trow_c = table + (size_t)xi * N1;
-    const float* trow_f = table + (size_t)(vocab + fi) * N1;
-    for (int n = 8 * threadIdx.x; n < N1; n += 8 * 256) {
-        float v[8];
-        const float4 a0 = *reinterpret_cast<const float4*>(trow_c + n), a1 = *reinterpret_cast<const float4*>(trow_c + n + 4);
-        const float4 g0 = *reinterpret_cast<const float4*>(b1 + n), g1 = *reinterpret_cast<const float4*>(b1 + n + 4);
-        v[0] = a0.x + g0.x; v[1] = a0.y + g0.y; v[2] = a0.z + g0.z; v[3] = a0.w + g0.w;
-        v[4] = a1.x + g1.x; v[5] = a1.y + g1.y; v[6] = a1.z + g1.z; v[7] = a1.w + g1.w;
-        if (n_fonts > 0) {
-            const float4 f0 = *reinterpret_cast<const float4*>(trow_f + n), f1 = *reinterpret_cast<const float4*>(trow_f + n + 4);
-            v[0] += f0.x; v[1] += f0.y; v[2] += f0.z; v[3] += f0.w; v[4] += f1.x; v[5] += f1.y; v[6] += f1.z; v[7] += f1.w;
-        }
-        bf16x8 w;
-#pragma unroll
-        for (int r = 0; r < 8; ++r) w[r] = (bf16_t)fmaxf(v[r], 0.f);
-        *reinterpret_cast<bf16x8*>(h1c + (size_t)c * ld1 + n) = w;
+    float* Ws = sm;
+    float* er = sm + 256 * (E + 1);
+    float* fr = er + CB_COMBOS * E;
+    const int c0 = blockIdx.x * CB_COMBOS, n0 = blockIdx.y * 256;
+    const int nn = min(256, N1 - n0), nc = min(CB_COMBOS, ncombo - c0);
+    const int E4 = E >> 2;
+    for (int i = threadIdx.x; i < nn * E4; i += 256) {
+        const float4 v = *reinterpret_cast<const float4*>(W1 + (size_t)n0 * E + 4 * i);
+        float* d = Ws + (i / E4) * (E + 1) + 4 * (i % E4);
+        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
     }
-    if ((int)threadIdx.x < E) {
-        float v = emb[(size_t)xi * E + threadIdx.x];
-        if (n_fonts > 0) v += femb[(size_t)fi * E + threadIdx.x];
-        h0c[(size_t)c * E + threadIdx.x] = (bf16_t)v;
+    for (int i = threadIdx.x; i < nc * E; i += 256) {
+        const int c = c0 + i / E, k = i % E, xi = c / nf, fi = c - xi * nf;
+        er[i] = emb[(size_t)xi * E + k];
+        fr[i] = n_fonts > 0 ? femb[(size_t)fi * E + k] : 0.f;
+        if (blockIdx.y == 0) h0c[(size_t)c * E + k] = (bf16_t)(n_fonts > 0 ? er[i] + fr[i] : er[i]);      // H0c = bf16(Emb[x] + Font[f])
+    }
+    __syncthreads();
+    if ((int)threadIdx.x >= nn) return;
+    const float* w = Ws + threadIdx.x * (E + 1);
+    // the first group of blocks also leaves W1^T as bf16 [E][N1] (the fused first-layer backward reads fc1's weights k-contiguous)
+    if (w1t && blockIdx.x == 0)
+        for (int k = 0; k < E; ++k) w1t[(size_t)k * N1 + n0 + threadIdx.x] = (bf16_t)w[k];
+    float tc[CB_COMBOS], tf[CB_COMBOS];
+#pragma unroll
+    for (int j = 0; j < CB_COMBOS; ++j) tc[j] = tf[j] = 0.f;
+    for (int k = 0; k < E; ++k) {
+        const float wv = w[k];
+#pragma unroll
+        for (int j = 0; j < CB_COMBOS; ++j) {             // (rows past nc read stale LDS; never stored)
+            tc[j] = fmaf(er[j * E + k], wv, tc[j]);
+            tf[j] = fmaf(fr[j * E + k], wv, tf[j]);
+        }
+    }
+    const float bias = b1[n0 + threadIdx.x];
+    for (int j = 0; j < nc; ++j) {
+        float v = tc[j] + bias;
+        if (n_fonts > 0) v += tf[j];
+        h1c[(size_t)(c0 + j) * ld1 + n0 + threadIdx.x] = (bf16_t)fmaxf(v, 0.f);
     }
 }
-// table (as glyph_l1_fwd) + combination rows + combination indices; h1c [vocab * max(n_fonts,1)][N1], h0c [..][E], cidx [B]
+// combination rows + combination indices (+ W1^T) in ONE launch; h1c [vocab * max(n_fonts,1)][ld1], h0c [..][E], cidx [B]
 hipError_t afr_launch_glyph_combo(const float* emb, const float* font_emb, const float* W1, const float* b1, const int64_t* x,
                                   const int64_t* font, int B, int E, int N1, int vocab, int n_fonts, float* table, void* h1c,
                                   int ld1, void* h0c, int* cidx, uint32_t* err_flag, hipStream_t s, void* w1t) {
     if (B <= 0) return hipSuccess;
     if ((N1 & 7) || (E & 7) || E > 256) return hipErrorInvalidValue;
-    const int rows = vocab + n_fonts;
-    const size_t tlds = (size_t)(256 * (E + 1) + GT_ROWS * E) * sizeof(float);
-    if (tlds > 48 * 1024) return hipErrorInvalidValue;                 // the combination path is planned for E <= 32 .. 40
-    hipLaunchKernelGGL(glyph_table_kernel, dim3((rows + GT_ROWS - 1) / GT_ROWS, (N1 + 255) / 256), dim3(256), tlds, s, emb, font_emb,
-                       W1, vocab, rows, E, N1, table, (bf16_t*)w1t);
-    const int tab_blocks = vocab * (n_fonts > 0 ? n_fonts : 1);
-    hipLaunchKernelGGL(glyph_combo_kernel, dim3(tab_blocks + (B + 255) / 256), dim3(256), 0, s, table, b1, emb, font_emb, x, font, B, E,
-                       N1, vocab, n_fonts, tab_blocks, (bf16_t*)h1c, ld1, (bf16_t*)h0c, cidx, err_flag);
+    (void)table;
+    const size_t lds = (size_t)(256 * (E + 1) + 2 * CB_COMBOS * E) * sizeof(float);
+    if (lds > 48 * 1024) return hipErrorInvalidValue;                  // the combination path is planned for E <= 32 .. 40
+    const int ncombo = vocab * (n_fonts > 0 ? n_fonts : 1);
+    const int combo_blocks = (ncombo + CB_COMBOS - 1) / CB_COMBOS;
+    hipLaunchKernelGGL(glyph_combo_kernel, dim3(combo_blocks + (B + 255) / 256, (N1 + 255) / 256), dim3(256), lds, s, W1, b1, emb, font_emb,
+                       x, font, B, E, N1, vocab, n_fonts, combo_blocks, (bf16_t*)h1c, ld1, (bf16_t*)h0c, cidx, (bf16_t*)w1t, err_flag);
     return hipGetLastError();
 }
 
