@@ -10,7 +10,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("AFR_LIB_PATH") or os.path.join(HERE, "csrc", "libafr.so")   # override: kernel A/B experiments
 
-AFR_KIND_SHEET, AFR_KIND_GLYPH = 0, 1
+AFR_KIND_SHEET, AFR_KIND_GLYPH, AFR_KIND_PIXEL = 0, 1, 2
 AFR_F32, AFR_BF16 = 0, 1
 AFR_TARGET_U8, AFR_TARGET_F32 = 0, 1
 AFR_MAX_HIDDEN = 8

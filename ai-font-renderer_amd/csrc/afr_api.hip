@@ -99,6 +99,11 @@ struct afr_plan {
     // products with a cooperative split-K tail apply AdamW themselves; adam_done lists the tensors they have updated
     bool step_on = false; float st_decay = 1.f, st_b1 = 0.f, st_b2 = 0.f, st_eps = 0.f, st_step = 0.f, st_rsqrt_bc2 = 1.f;
     std::vector<int64_t> adam_done;
+    // pixel-token transformer (AFR_KIND_PIXEL): per-block parameter offsets and the forward's workspace
+    struct PixBlock { int64_t ln1g, ln1b, win, bin, wo, bo, ln2g, ln2b, w1, b1, w2, b2; };
+    std::vector<PixBlock> pix;
+    int64_t px_pos = 0, px_emb = 0, px_font = -1, px_lnfg = 0, px_lnfb = 0, px_wout = 0, px_bout = 0;
+    size_t o_ctx = 0, o_kv = 0, o_h = 0, o_n = 0, o_q = 0, o_o = 0, o_a = 0, o_f = 0;
     // glyph layer table
     struct Layer { int N, K; int64_t w_off, b_off; int sk = 1; size_t o_slab_w = 0, o_slab_b = 0;
                    size_t o_cnt = 0; int n_cnt = 0; unsigned coop_epoch = 0; };   // cooperative split-K: per-tile arrival counters, launches so far
@@ -304,6 +309,41 @@ extern "C" int afr_plan_create(const afr_config* c, afr_plan** out) {
                 p->o_w2t = carve((size_t)Pix * c->hidden[0] * 2);
             }
         }
+    } else if (c->kind == AFR_KIND_PIXEL) {
+        const int d = E, ff = c->fc_dim, T = Pix, nf = c->n_fonts > 0 ? c->n_fonts : 0, C = nf > 0 ? 2 : 1;
+        if (d > 512 || d % 64 || c->heads * 64 != d || ff <= 0 || ff % 8 || c->n_hidden < 1 || c->n_hidden > AFR_MAX_HIDDEN)
+            { delete p; return fail(AFR_EUNSUPPORTED, "pixel transformer: d_model = 64 * heads <= 512, ff a multiple of 8, 1..%d blocks", AFR_MAX_HIDDEN); }
+        add_param(p, "positional_encoding", {T, d});
+        add_param(p, "embedding.weight", {c->vocab, d});
+        if (nf > 0) add_param(p, "font_embedding.weight", {nf, d});
+        char nm[64];
+        for (int l = 0; l < c->n_hidden; ++l) {
+            afr_plan::PixBlock b;
+            auto addp = [&](const char* suffix, std::initializer_list<int64_t> shape) { snprintf(nm, sizeof nm, "layers.%d.%s", l, suffix); add_param(p, nm, shape); return p->params.back().off; };
+            b.ln1g = addp("ln1.weight", {d}); b.ln1b = addp("ln1.bias", {d});
+            b.win = addp("attn.in_proj_weight", {3 * d, d}); b.bin = addp("attn.in_proj_bias", {3 * d});
+            b.wo = addp("attn.out_proj.weight", {d, d}); b.bo = addp("attn.out_proj.bias", {d});
+            b.ln2g = addp("ln2.weight", {d}); b.ln2b = addp("ln2.bias", {d});
+            b.w1 = addp("fc1.weight", {ff, d}); b.b1 = addp("fc1.bias", {ff});
+            b.w2 = addp("fc2.weight", {d, ff}); b.b2 = addp("fc2.bias", {d});
+            p->pix.push_back(b);
+        }
+        add_param(p, "ln_f.weight", {d}); add_param(p, "ln_f.bias", {d});
+        add_param(p, "fc_output.weight", {1, d}); add_param(p, "fc_output.bias", {1});
+        p->px_pos = off_of(p, "positional_encoding"); p->px_emb = off_of(p, "embedding.weight");
+        p->px_font = nf > 0 ? off_of(p, "font_embedding.weight") : -1;
+        p->px_lnfg = off_of(p, "ln_f.weight"); p->px_lnfb = off_of(p, "ln_f.bias");
+        p->px_wout = off_of(p, "fc_output.weight"); p->px_bout = off_of(p, "fc_output.bias");
+        const size_t rows = B * (size_t)T;
+        if (c->dtype == AFR_BF16 && (rows * (size_t)(ff > d ? ff : d) * 2 >= (1ull << 31)))
+            { delete p; return fail(AFR_EUNSUPPORTED, "max_batch %d x %d tokens: an activation operand would reach 2 GiB in bf16", c->max_batch, T); }
+        if (c->dtype == AFR_BF16) p->o_shadow = carve((size_t)p->total * 2);
+        p->o_err = carve(256);
+        p->o_ctx = carve(B * C * d * ab); p->o_kv = carve(B * C * 2 * d * ab);
+        p->o_h = carve(rows * d * sizeof(float));
+        p->o_n = carve(rows * d * ab); p->o_q = carve(rows * d * ab); p->o_o = carve(rows * d * ab); p->o_a = carve(rows * d * ab);
+        p->o_f = carve(rows * ff * ab);
+        p->o_u = carve(rows * sizeof(float));
     } else {
         delete p;
         return fail(AFR_EINVAL, "unknown model kind %d", c->kind);
@@ -726,6 +766,48 @@ static int forward_impl(afr_plan* p, const int64_t* x, const int64_t* font, int 
         if (rc) return rc;
         p->last_L = Lc;
         p->last_ldx = L;
+    } else if (c.kind == AFR_KIND_PIXEL) {
+        // BASELINE configs[4] (oracle.pixel_forward): forward only.  Token-wise kernels in pixel.hip, every Linear
+        // on the GEMM kernels; the residual stream h stays f32.
+        if (training || fl) return fail(AFR_EUNSUPPORTED, "the pixel-token transformer has no training path yet (forward only)");
+        if (c.n_fonts > 0 && !font) return fail(AFR_EINVAL, "font ids are required when n_fonts > 0");
+        const int d = c.embed_dim, ff = c.fc_dim, T = Pix, C = c.n_fonts > 0 ? 2 : 1;
+        const long long rows = (long long)B * T;
+        float* h = (float*)(p->ws + p->o_h);
+        void *ctx = p->ws + p->o_ctx, *kv = p->ws + p->o_kv, *n = p->ws + p->o_n, *q = p->ws + p->o_q, *o = p->ws + p->o_o, *a = p->ws + p->o_a, *f = p->ws + p->o_f;
+        {
+            ProfScope ps(p, s, "pixel_ctx", 0.0, 0.0);
+            HIPCHK(afr_launch_pixel_ctx(c.dtype, p->P + p->px_emb, p->px_font >= 0 ? p->P + p->px_font : nullptr, x, font, B, d, c.vocab, c.n_fonts, ctx, err, s));
+        }
+        int rc;
+        for (int l = 0; l < c.n_hidden; ++l) {
+            const afr_plan::PixBlock& b = p->pix[l];
+            {
+                ProfScope ps(p, s, "pixel_add_ln", 0.0, (double)rows * d * (8.0 + p->act_bytes));
+                HIPCHK(afr_launch_pixel_add_ln(c.dtype, h, l == 0 ? p->P + p->px_pos : nullptr, l == 0 ? nullptr : a, p->P + b.ln1g, p->P + b.ln1b, n, rows, T, d, c.ln_eps, s));
+            }
+            // packed in-projection (model.py:144): rows [0, d) of in_proj_weight make q from the pixel tokens, rows [d, 3d) k | v from the context
+            if ((rc = run_gemm(p, s, AFR_GEMM_BIAS | ob, n, weight_ptr(p, b.win), q, p->P + b.bin, nullptr, (int)rows, d, d, d, d, d, 0, 1, 0))) return rc;
+            if ((rc = run_gemm(p, s, AFR_GEMM_BIAS | ob, ctx, weight_ptr(p, b.win + (int64_t)d * d), kv, p->P + b.bin + d, nullptr, B * C, 2 * d, d, d, d, 2 * d, 0, 1, 0))) return rc;
+            {
+                ProfScope ps(p, s, "pixel_attn", 0.0, (double)rows * d * 2.0 * p->act_bytes);
+                HIPCHK(afr_launch_pixel_attn(c.dtype, q, kv, o, rows, T, d, c.heads, C, s));
+            }
+            if ((rc = run_gemm(p, s, AFR_GEMM_BIAS | ob, o, weight_ptr(p, b.wo), a, p->P + b.bo, nullptr, (int)rows, d, d, d, d, d, 0, 1, 0))) return rc;
+            {
+                ProfScope ps(p, s, "pixel_add_ln", 0.0, (double)rows * d * (8.0 + 2.0 * p->act_bytes));
+                HIPCHK(afr_launch_pixel_add_ln(c.dtype, h, nullptr, a, p->P + b.ln2g, p->P + b.ln2b, n, rows, T, d, c.ln_eps, s));
+            }
+            if ((rc = run_gemm(p, s, AFR_GEMM_BIAS | AFR_GEMM_RELU | ob, n, weight_ptr(p, b.w1), f, p->P + b.b1, nullptr, (int)rows, ff, d, d, d, ff, 0, 1, 0))) return rc;
+            if ((rc = run_gemm(p, s, AFR_GEMM_BIAS | ob, f, weight_ptr(p, b.w2), a, p->P + b.b2, nullptr, (int)rows, d, ff, ff, ff, d, 0, 1, 0))) return rc;
+        }
+        {
+            ProfScope ps(p, s, "pixel_head", 0.0, (double)rows * d * (8.0 + p->act_bytes));
+            HIPCHK(afr_launch_pixel_head(c.dtype, h, a, p->P + p->px_lnfg, p->P + p->px_lnfb, p->P + p->px_wout, p->P + p->px_bout, (float*)u, y, rows, d, c.ln_eps, s));
+        }
+        p->last_x = x; p->last_font = font; p->last_B = B; p->last_L = 1; p->last_training = 0; p->last_step = step;
+        p->next_stage = 0; p->have_du = false; p->combo_on = false; p->mbits_on = false;
+        return AFR_OK;
     } else {
         if (c.n_fonts > 0 && !font) return fail(AFR_EINVAL, "font ids are required when n_fonts > 0");
         void* h = p->ws + p->o_act[0];
@@ -1174,6 +1256,7 @@ extern "C" int afr_train_step(afr_plan* p, const int64_t* x, const int64_t* font
     if (tdtype != AFR_TARGET_U8 && tdtype != AFR_TARGET_F32) return fail(AFR_EINVAL, "bad target dtype");
     if (mean_elems <= 0) return fail(AFR_EINVAL, "mean_elems must be positive");
     if (!p || !p->P) return fail(AFR_ESTATE, "plan has no bound parameters");
+    if (p->cfg.kind == AFR_KIND_PIXEL) return fail(AFR_EUNSUPPORTED, "the pixel-token transformer has no training path yet (forward only)");
     DevGuard dg(p->device);
     if (p->fused1 && !(p->cfg.reserved & 4)) {
         // small glyph net: forward + loss + backward in ONE launch, then the grouped reduce (with AdamW when stepping here)

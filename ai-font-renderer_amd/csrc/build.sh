@@ -5,7 +5,7 @@ cd "$(dirname "$0")"
 FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wall -Wno-unused-function $*"
 mkdir -p build
 pids=()
-for f in gemm elementwise sheet glyph_fused afr_api; do
+for f in gemm elementwise sheet glyph_fused pixel afr_api; do
   if [ ! -f build/$f.o ] || [ $f.hip -nt build/$f.o ] || [ afr_common.h -nt build/$f.o ] || [ ../../include/afr.h -nt build/$f.o ]; then
     hipcc $FLAGS -c $f.hip -o build/$f.o &
     pids+=($!)
@@ -23,5 +23,5 @@ if grep -E "ScratchSize \[bytes/lane\]: [1-9]" build/gemm.remarks > /dev/null; t
   grep -B4 -E "ScratchSize \[bytes/lane\]: [1-9]" build/gemm.remarks | grep -E "Function Name|ScratchSize" >&2
   exit 1
 fi
-hipcc --offload-arch=gfx950 -shared -fPIC -o libafr.so build/gemm.o build/elementwise.o build/sheet.o build/glyph_fused.o build/afr_api.o
+hipcc --offload-arch=gfx950 -shared -fPIC -o libafr.so build/gemm.o build/elementwise.o build/sheet.o build/glyph_fused.o build/pixel.o build/afr_api.o
 echo "built $(pwd)/libafr.so"

@@ -47,7 +47,13 @@ __device__ __forceinline__ void tile_coords(const GemmParams& p, int BM, int BN,
     const int s0 = grp * G;
     const int gs = min(G, ts - s0);
     const int rr = t - grp * G * tf;
-    const int sidx = s0 + rr % gs, fidx = rr / gs;
+    // Inside a group the FAST index runs fastest when the fast dimension is only a few tiles (R0's fc_output: 4 row tiles of
+    // the batch against 150 column tiles of the 246 MB weight): the tiles that share one big-operand tile are then adjacent in
+    // the walk, so an XCD range that does not start on a group boundary (600 tiles / 8 XCDs = 75, groups of 32) shares ONE
+    // big-operand tile with its neighbour instead of a whole group's -- with the slow index fastest every straddled group's
+    // weight tiles were fetched by two XCDs (PMC: 743 MB read against 259 MB of operands).
+    const bool fast_first = tf <= 8;
+    const int sidx = fast_first ? s0 + rr / tf : s0 + rr % gs, fidx = fast_first ? rr % tf : rr / gs;
     tm = n_slow ? fidx : sidx;
     tn = n_slow ? sidx : fidx;
 }
@@ -1222,7 +1228,6 @@ __device__ __forceinline__ void gemm_bf16_256_body(const GemmParams& p, const in
         const __amdgpu_buffer_rsrc_t rws = __builtin_amdgcn_make_buffer_rsrc(p.coop_ws, 0, 0x7FFFFFFF, 0x00020000);
         typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
         const unsigned tile_b = (unsigned)T * (unsigned)S * (8u * 32u * 1024u);          // < 2 GiB: checked by the launcher
-        const bool adam = p.ad_p != nullptr;
         float* Wt = reinterpret_cast<float*>(smem) + wave * 4096;
         {
             const unsigned mine = tile_b + ((unsigned)z * 8u + (unsigned)wave) * (32u * 1024u) + (unsigned)lane * 16u;
@@ -1579,16 +1584,39 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8(GemmParams p) {
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    auto stage = [&](int t, int slot) {
+    // Interior blocks (whole tile inside M x N, K a multiple of 128) address their pieces the FAST way of the bf16 ring: the
+    // lane-dependent part of a piece's source offset is the same for all of a wave's pieces of an operand (row-in-piece and
+    // chunk swizzle depend on the lane only), so it is ONE VGPR per operand; which piece and which K-tile are a wave-uniform
+    // SGPR offset.  No per-piece address arithmetic or bounds selects inside the K loop.
+    const bool fast = (m0 + BM <= p.M) && (n0 + BN <= p.N) && (p.K % BK == 0);
+    unsigned fvA, fvB;
+    {
+        const int r8 = lane >> 3, c = (lane & 7) ^ (r8 & 7), ga = wave * 4, gb = wave * 2;
+        fvA = (unsigned)((size_t)(m0 + (ga >> 4) * 128 + (ga & 15) * 8 + r8) * p.lda + 16 * c);
+        fvB = (unsigned)((size_t)(n0 + gb * 8 + r8) * p.ldb + 16 * c);
+    }
+    const unsigned fpA = 8u * p.lda, fpB = 8u * p.ldb;
+    auto dma_s = [&](i32x4 rsrc, unsigned lds_addr, unsigned voff, unsigned soff) {
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 3\n\tbuffer_load_dwordx4 %1, %4, %3 offen lds\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(voff), "s"(lds_addr), "s"(soff), "s"(rsrc) : "memory");
+    };
+    // piece q of the wave (0..3: A, 4..5: B) of K-tile t into ring slot `slot`
+    auto stage_piece = [&](int t, int slot, int q) {
         const unsigned S = lds0 + slot * STAGE_BYTES;
-        const int k0 = t * BK;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int g = wave * 4 + i;
-            stage_inst8(rA, S + (g >> 4) * SUB, p.lda, p.M, m0 + (g >> 4) * 128, k0, p.K, g & 15, lane);
+        if (q < 4) {
+            const int g = wave * 4 + q;
+            if (fast) dma_s(rA, S + (g >> 4) * SUB + (g & 15) * 1024, fvA, (unsigned)t * BK + (unsigned)q * fpA);
+            else stage_inst8(rA, S + (g >> 4) * SUB, p.lda, p.M, m0 + (g >> 4) * 128, t * BK, p.K, g & 15, lane);
+        } else {
+            const int i = q - 4;
+            if (fast) dma_s(rB, S + 2 * SUB + (wave * 2 + i) * 1024, fvB, (unsigned)t * BK + (unsigned)i * fpB);
+            else stage_inst8(rB, S + 2 * SUB, p.ldb, p.N, n0, t * BK, p.K, wave * 2 + i, lane);
         }
+    };
+    auto stage = [&](int t, int slot) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) stage_inst8(rB, S + 2 * SUB, p.ldb, p.N, n0, k0, p.K, wave * 2 + i, lane);
+        for (int q = 0; q < 6; ++q) stage_piece(t, slot, q);
     };
 #pragma unroll
     for (int t = 0; t < 3; ++t)
@@ -1607,21 +1635,33 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8(GemmParams p) {
     // one K-tile: [tile t+1 has landed -> barrier -> refill the slot of tile t (everybody holds it in registers) -> issue the
     // fragment reads of tile t+1 into the OTHER register set] under the 16 MFMAs of tile t -> the reads are complete
     auto step = [&](int t, int slot, const i32x8 (&fa)[4], const i32x8 (&fb)[4], i32x8 (&na)[4], i32x8 (&nb)[4]) {
-        if (t + 1 < nt) {
+        const bool more = t + 1 < nt, refill = t + 3 < nt;
+        if (more) {
             // outstanding, oldest first: tile t+1, tile t+2 (6 pieces each)
             if (t + 2 < nt) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
-            if (t + 3 < nt) stage(t + 3, slot);
-            read_tile(slot + 1 == 3 ? 0 : slot + 1, na, nb);
         }
+        const char* Sn = smem + (slot + 1 == 3 ? 0 : slot + 1) * STAGE_BYTES;
         __builtin_amdgcn_s_setprio(1);
-        // operands swapped as in the bf16 kernels: D'[n][m], a lane owns 4 consecutive n of one row m
+        // operands swapped as in the bf16 kernels: D'[n][m], a lane owns 4 consecutive n of one row m.  The refill's DMA pieces
+        // and the next tile's fragment reads go out BETWEEN the rows of MFMAs (an LDS-DMA piece holds its wave ~100 cycles:
+        // issued in one burst ahead of the MFMAs, both waves of a SIMD stall together)
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 4; ++i) {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fb[j], fa[i], acc[i][j], 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+            if (refill) {
+#pragma unroll
+                for (int q = (i * 6) / 4; q < ((i + 1) * 6) / 4; ++q) stage_piece(t + 3, slot, q);
+            }
+            if (more) {
+                na[i] = read_frag8(Sn + (wm >> 1) * SUB, (wm & 1) * 64 + 16 * i, lane);
+                nb[i] = read_frag8(Sn + 2 * SUB, wn * 64 + 16 * i, lane);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
         __builtin_amdgcn_s_setprio(0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);

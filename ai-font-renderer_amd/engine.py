@@ -10,7 +10,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .config import GlyphConfig, SheetConfig
+from .config import GlyphConfig, PixelConfig, SheetConfig
 
 _DT = {"f32": _lib.AFR_F32, "fp32": _lib.AFR_F32, "float32": _lib.AFR_F32, "bf16": _lib.AFR_BF16, "bfloat16": _lib.AFR_BF16}
 
@@ -31,7 +31,7 @@ def make_afr_config(cfg, dtype, max_batch, seed=42, rank=0, flags=0):
     c.dtype = _DT[dtype]
     c.max_batch = int(max_batch)
     c.vocab = cfg.vocab
-    c.embed_dim = cfg.embed_dim
+    c.embed_dim = getattr(cfg, "embed_dim", 0)      # (PixelConfig: d_model, set below)
     c.seed = int(seed)
     c.rank = int(rank)
     if isinstance(cfg, SheetConfig):
@@ -46,6 +46,11 @@ def make_afr_config(cfg, dtype, max_batch, seed=42, rank=0, flags=0):
         for i, h in enumerate(cfg.hidden):
             c.hidden[i] = h
         c.n_fonts = cfg.n_fonts
+    elif isinstance(cfg, PixelConfig):
+        c.kind = _lib.AFR_KIND_PIXEL                 # BASELINE configs[4]: forward only so far (include/afr.h)
+        c.embed_dim = cfg.d_model
+        c.out_h, c.out_w = cfg.out_h, cfg.out_w
+        c.heads, c.fc_dim, c.n_hidden, c.n_fonts, c.ln_eps = cfg.heads, cfg.ff_dim, cfg.layers, cfg.n_fonts, cfg.ln_eps
     else:
         raise TypeError(f"unknown config {type(cfg)}")
     return c
@@ -167,7 +172,7 @@ class Engine:
         self._keep = (x, font)
         if y is None:
             return None
-        h, w = (self.cfg.sheet_h, self.cfg.sheet_w) if isinstance(self.cfg, SheetConfig) else (self.cfg.out_h, self.cfg.out_w)
+        h, w = (self.cfg.sheet_h, self.cfg.sheet_w) if isinstance(self.cfg, SheetConfig) else (self.cfg.out_h, self.cfg.out_w)     # glyph / pixel
         return y.view(B, h, w)
 
     def _target(self, target):
