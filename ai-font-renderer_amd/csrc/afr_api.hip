@@ -103,11 +103,15 @@ struct afr_plan {
     struct PixBlock { int64_t ln1g, ln1b, win, bin, wo, bo, ln2g, ln2b, w1, b1, w2, b2; };
     std::vector<PixBlock> pix;
     int64_t px_pos = 0, px_emb = 0, px_font = -1, px_lnfg = 0, px_lnfb = 0, px_wout = 0, px_bout = 0;
-    size_t o_ctx = 0, o_kv = 0, o_h = 0, o_n = 0, o_q = 0, o_o = 0, o_a = 0, o_f = 0;
+    struct PixSave { size_t hin, h1, n1, q, o, n2, kv, f, ln1p, ln2p; };      // per block: what its backward needs + its LayerNorm partial slabs
+    std::vector<PixSave> pxs;
+    size_t o_ctx = 0, o_a = 0, o_hf = 0, o_dh = 0, o_dht = 0, o_df = 0, o_dn = 0, o_dq = 0, o_dkvp = 0, o_dkv = 0, o_dkvt = 0, o_dctxt = 0,
+           o_dctx = 0, o_headp = 0;
     // glyph layer table
     struct Layer { int N, K; int64_t w_off, b_off; int sk = 1; size_t o_slab_w = 0, o_slab_b = 0;
                    size_t o_cnt = 0; int n_cnt = 0; unsigned coop_epoch = 0; };   // cooperative split-K: per-tile arrival counters, launches so far
     std::vector<Layer> layers;
+    std::vector<Layer> pxl;          // the 5 Linears of every block as weight-gradient descriptors: q, kv, out-proj, fc1, fc2
     int64_t emb_off = 0, font_off = 0;
     // sheet offsets
     int64_t s_pos = 0, s_emb = 0, s_win = 0, s_bin = 0, s_wo = 0, s_bo = 0, s_g = 0, s_b = 0, s_w1 = 0, s_b1 = 0, s_wout = 0, s_bout = 0;
@@ -339,11 +343,35 @@ extern "C" int afr_plan_create(const afr_config* c, afr_plan** out) {
             { delete p; return fail(AFR_EUNSUPPORTED, "max_batch %d x %d tokens: an activation operand would reach 2 GiB in bf16", c->max_batch, T); }
         if (c->dtype == AFR_BF16) p->o_shadow = carve((size_t)p->total * 2);
         p->o_err = carve(256);
-        p->o_ctx = carve(B * C * d * ab); p->o_kv = carve(B * C * 2 * d * ab);
-        p->o_h = carve(rows * d * sizeof(float));
-        p->o_n = carve(rows * d * ab); p->o_q = carve(rows * d * ab); p->o_o = carve(rows * d * ab); p->o_a = carve(rows * d * ab);
-        p->o_f = carve(rows * ff * ab);
+        p->o_loss = carve((1040 + 1040) * sizeof(float));
+        p->o_ctx = carve(B * C * d * ab);
+        const size_t nbp = (size_t)afr_pixel_bwd_blocks((long long)rows);
+        for (int l = 0; l < c->n_hidden; ++l) {
+            afr_plan::PixSave sv;
+            sv.hin = carve(rows * d * sizeof(float)); sv.h1 = carve(rows * d * sizeof(float));
+            sv.n1 = carve(rows * d * ab); sv.q = carve(rows * d * ab); sv.o = carve(rows * d * ab); sv.n2 = carve(rows * d * ab);
+            sv.kv = carve(B * C * 2 * d * ab); sv.f = carve(rows * ff * ab);
+            sv.ln1p = carve(nbp * 2 * d * sizeof(float)); sv.ln2p = carve(nbp * 2 * d * sizeof(float));
+            p->pxs.push_back(sv);
+            const afr_plan::PixBlock& b = p->pix[l];
+            const struct { int N, K; int64_t w, bo; long long red; } lin[5] = {
+                {d, d, b.win, b.bin, (long long)rows}, {2 * d, d, b.win + (int64_t)d * d, b.bin + d, (long long)(B * C)}, {d, d, b.wo, b.bo, (long long)rows},
+                {ff, d, b.w1, b.b1, (long long)rows}, {d, ff, b.w2, b.b2, (long long)rows}};
+            for (const auto& q_ : lin) {
+                afr_plan::Layer ly; ly.N = q_.N; ly.K = q_.K; ly.w_off = q_.w; ly.b_off = q_.bo;
+                ly.sk = choose_splitk(q_.N, q_.K, (int)(q_.red > 0x7fffffff ? 0x7fffffff : q_.red));
+                if (ly.sk > 1) { ly.o_slab_w = carve((size_t)ly.sk * q_.N * q_.K * sizeof(float)); ly.o_slab_b = carve((size_t)ly.sk * q_.N * sizeof(float)); }
+                p->pxl.push_back(ly);
+            }
+        }
+        p->o_a = carve(rows * d * ab); p->o_hf = carve(rows * d * sizeof(float));
         p->o_u = carve(rows * sizeof(float));
+        p->o_dh = carve(rows * d * sizeof(float)); p->o_dht = c->dtype == AFR_BF16 ? carve(rows * d * ab) : 0;
+        p->o_df = carve(rows * ff * ab); p->o_dn = carve(rows * d * ab); p->o_dq = carve(rows * d * ab);
+        const size_t chunks = ((size_t)T + afr_pixel_attn_chunk(T) - 1) / afr_pixel_attn_chunk(T);
+        p->o_dkvp = carve(B * chunks * 4 * d * sizeof(float)); p->o_dkv = carve(B * 4 * d * sizeof(float)); p->o_dkvt = carve(B * C * 2 * d * ab);
+        p->o_dctxt = carve(B * C * d * ab); p->o_dctx = carve(B * C * d * sizeof(float));
+        p->o_headp = carve(nbp * 4 * d * sizeof(float));
     } else {
         delete p;
         return fail(AFR_EINVAL, "unknown model kind %d", c->kind);
@@ -767,14 +795,13 @@ static int forward_impl(afr_plan* p, const int64_t* x, const int64_t* font, int 
         p->last_L = Lc;
         p->last_ldx = L;
     } else if (c.kind == AFR_KIND_PIXEL) {
-        // BASELINE configs[4] (oracle.pixel_forward): forward only.  Token-wise kernels in pixel.hip, every Linear
-        // on the GEMM kernels; the residual stream h stays f32.
-        if (training || fl) return fail(AFR_EUNSUPPORTED, "the pixel-token transformer has no training path yet (forward only)");
+        // BASELINE configs[4] (oracle.pixel_forward).  Token-wise kernels in pixel.hip, every Linear on the GEMM
+        // kernels; the residual stream stays f32; every block keeps what its backward needs (its two residual inputs, LayerNorm
+        // outputs, q, k|v, attention output, ReLU output).  No dropout in this model: `training` changes nothing.
         if (c.n_fonts > 0 && !font) return fail(AFR_EINVAL, "font ids are required when n_fonts > 0");
         const int d = c.embed_dim, ff = c.fc_dim, T = Pix, C = c.n_fonts > 0 ? 2 : 1;
         const long long rows = (long long)B * T;
-        float* h = (float*)(p->ws + p->o_h);
-        void *ctx = p->ws + p->o_ctx, *kv = p->ws + p->o_kv, *n = p->ws + p->o_n, *q = p->ws + p->o_q, *o = p->ws + p->o_o, *a = p->ws + p->o_a, *f = p->ws + p->o_f;
+        void *ctx = p->ws + p->o_ctx, *a = p->ws + p->o_a;
         {
             ProfScope ps(p, s, "pixel_ctx", 0.0, 0.0);
             HIPCHK(afr_launch_pixel_ctx(c.dtype, p->P + p->px_emb, p->px_font >= 0 ? p->P + p->px_font : nullptr, x, font, B, d, c.vocab, c.n_fonts, ctx, err, s));
@@ -782,12 +809,16 @@ static int forward_impl(afr_plan* p, const int64_t* x, const int64_t* font, int 
         int rc;
         for (int l = 0; l < c.n_hidden; ++l) {
             const afr_plan::PixBlock& b = p->pix[l];
+            const afr_plan::PixSave& sv = p->pxs[l];
+            float *hin = (float*)(p->ws + sv.hin), *h1 = (float*)(p->ws + sv.h1);
+            void *n1 = p->ws + sv.n1, *q = p->ws + sv.q, *o = p->ws + sv.o, *n2 = p->ws + sv.n2, *kv = p->ws + sv.kv, *f = p->ws + sv.f;
             {
                 ProfScope ps(p, s, "pixel_add_ln", 0.0, (double)rows * d * (8.0 + p->act_bytes));
-                HIPCHK(afr_launch_pixel_add_ln(c.dtype, h, l == 0 ? p->P + p->px_pos : nullptr, l == 0 ? nullptr : a, p->P + b.ln1g, p->P + b.ln1b, n, rows, T, d, c.ln_eps, s));
+                HIPCHK(afr_launch_pixel_add_ln(c.dtype, l == 0 ? nullptr : (const float*)(p->ws + p->pxs[l - 1].h1), hin, l == 0 ? p->P + p->px_pos : nullptr,
+                                               l == 0 ? nullptr : a, p->P + b.ln1g, p->P + b.ln1b, n1, rows, T, d, c.ln_eps, s));
             }
             // packed in-projection (model.py:144): rows [0, d) of in_proj_weight make q from the pixel tokens, rows [d, 3d) k | v from the context
-            if ((rc = run_gemm(p, s, AFR_GEMM_BIAS | ob, n, weight_ptr(p, b.win), q, p->P + b.bin, nullptr, (int)rows, d, d, d, d, d, 0, 1, 0))) return rc;
+            if ((rc = run_gemm(p, s, AFR_GEMM_BIAS | ob, n1, weight_ptr(p, b.win), q, p->P + b.bin, nullptr, (int)rows, d, d, d, d, d, 0, 1, 0))) return rc;
             if ((rc = run_gemm(p, s, AFR_GEMM_BIAS | ob, ctx, weight_ptr(p, b.win + (int64_t)d * d), kv, p->P + b.bin + d, nullptr, B * C, 2 * d, d, d, d, 2 * d, 0, 1, 0))) return rc;
             {
                 ProfScope ps(p, s, "pixel_attn", 0.0, (double)rows * d * 2.0 * p->act_bytes);
@@ -796,17 +827,24 @@ static int forward_impl(afr_plan* p, const int64_t* x, const int64_t* font, int 
             if ((rc = run_gemm(p, s, AFR_GEMM_BIAS | ob, o, weight_ptr(p, b.wo), a, p->P + b.bo, nullptr, (int)rows, d, d, d, d, d, 0, 1, 0))) return rc;
             {
                 ProfScope ps(p, s, "pixel_add_ln", 0.0, (double)rows * d * (8.0 + 2.0 * p->act_bytes));
-                HIPCHK(afr_launch_pixel_add_ln(c.dtype, h, nullptr, a, p->P + b.ln2g, p->P + b.ln2b, n, rows, T, d, c.ln_eps, s));
+                HIPCHK(afr_launch_pixel_add_ln(c.dtype, hin, h1, nullptr, a, p->P + b.ln2g, p->P + b.ln2b, n2, rows, T, d, c.ln_eps, s));
             }
-            if ((rc = run_gemm(p, s, AFR_GEMM_BIAS | AFR_GEMM_RELU | ob, n, weight_ptr(p, b.w1), f, p->P + b.b1, nullptr, (int)rows, ff, d, d, d, ff, 0, 1, 0))) return rc;
+            if ((rc = run_gemm(p, s, AFR_GEMM_BIAS | AFR_GEMM_RELU | ob, n2, weight_ptr(p, b.w1), f, p->P + b.b1, nullptr, (int)rows, ff, d, d, d, ff, 0, 1, 0))) return rc;
             if ((rc = run_gemm(p, s, AFR_GEMM_BIAS | ob, f, weight_ptr(p, b.w2), a, p->P + b.b2, nullptr, (int)rows, d, ff, ff, ff, d, 0, 1, 0))) return rc;
         }
         {
             ProfScope ps(p, s, "pixel_head", 0.0, (double)rows * d * (8.0 + p->act_bytes));
-            HIPCHK(afr_launch_pixel_head(c.dtype, h, a, p->P + p->px_lnfg, p->P + p->px_lnfb, p->P + p->px_wout, p->P + p->px_bout, (float*)u, y, rows, d, c.ln_eps, s));
+            HIPCHK(afr_launch_pixel_head(c.dtype, (const float*)(p->ws + p->pxs.back().h1), (float*)(p->ws + p->o_hf), a, p->P + p->px_lnfg, p->P + p->px_lnfb,
+                                         p->P + p->px_wout, p->P + p->px_bout, (float*)u, y, rows, d, c.ln_eps, s));
         }
-        p->last_x = x; p->last_font = font; p->last_B = B; p->last_L = 1; p->last_training = 0; p->last_step = step;
-        p->next_stage = 0; p->have_du = false; p->combo_on = false; p->mbits_on = false;
+        p->last_x = x; p->last_font = font; p->last_B = B; p->last_L = 1; p->last_training = training; p->last_step = step;
+        p->next_stage = 0; p->combo_on = false; p->mbits_on = false;
+        p->have_du = false;
+        if (fl) {        // the loss on the f32 pre-clamp output (model.py:156,268-270): du in place over u
+            ProfScope ps(p, s, "mse_grad", 0.0, (double)rows * 9.0);
+            HIPCHK(afr_launch_mse_grad(AFR_F32, u, fl->target, fl->tdtype, u, B, Pix, fl->mean_elems, fl->loss_accum, (float*)(p->ws + p->o_loss), s));
+            p->have_du = true;
+        }
         return AFR_OK;
     } else {
         if (c.n_fonts > 0 && !font) return fail(AFR_EINVAL, "font ids are required when n_fonts > 0");
@@ -883,8 +921,8 @@ extern "C" int afr_loss_grad(afr_plan* p, const void* target, int tdtype, int B,
     void* u = p->ws + p->o_u;
     const double tb = tdtype == AFR_TARGET_U8 ? 1.0 : 4.0;
     ProfScope ps(p, s, "mse_grad", 0.0, (double)B * Pix * (2.0 * p->act_bytes + tb));
-    HIPCHK(afr_launch_mse_grad(p->cfg.dtype, u, target, tdtype, u, B, Pix, mean_elems, loss_accum,
-                               (float*)(p->ws + p->o_loss), s));
+    HIPCHK(afr_launch_mse_grad(p->cfg.kind == AFR_KIND_PIXEL ? AFR_F32 : p->cfg.dtype, u, target, tdtype, u, B, Pix, mean_elems, loss_accum,
+                               (float*)(p->ws + p->o_loss), s));      // (the pixel transformer's pre-clamp output is f32 in both modes)
     p->have_du = true;
     return AFR_OK;
 }
@@ -894,7 +932,7 @@ extern "C" int afr_set_output_grad(afr_plan* p, const float* dy, int B, void* st
     DevGuard dg(p->device);
     if (!dy) return fail(AFR_EINVAL, "dy is null");
     if (B != p->last_B) return fail(AFR_ESTATE, "batch %d does not match the last forward (%d)", B, p->last_B);
-    HIPCHK(afr_launch_clamp_bwd(p->cfg.dtype, p->ws + p->o_u, dy, (long long)B * p->cfg.out_h * p->cfg.out_w, (hipStream_t)stream));
+    HIPCHK(afr_launch_clamp_bwd(p->cfg.kind == AFR_KIND_PIXEL ? AFR_F32 : p->cfg.dtype, p->ws + p->o_u, dy, (long long)B * p->cfg.out_h * p->cfg.out_w, (hipStream_t)stream));
     p->have_du = true;
     return AFR_OK;
 }
@@ -903,7 +941,92 @@ extern "C" int afr_set_output_grad(afr_plan* p, const float* dy, int B, void* st
 // Backward runs in STAGES, last layer first; each stage finishes a contiguous range of the flat gradient buffer
 // (its own slab reduction included), so a data-parallel caller can start the all-reduce of that range while the
 // next stage computes.  Glyph: one stage per Linear (the first layer's stage also does the embedding tables).
-// Sheet: stage 0 = fc_output (dW + db), stage 1 = dz GEMM + fused front-end backward.
+// Sheet: stage 0 = fc_output (dW + db), stage 1 = dz GEMM + fused front-end backward.  Pixel transformer: one stage.
+
+// Backward of the pixel-token transformer (reverse of forward_impl's AFR_KIND_PIXEL branch; oracle.pixel_backward): du (f32,
+// left in the u buffer by the loss) -> every parameter gradient.  Linears: the dW (+ fused db) and dX GEMMs of gemm.hip;
+// token-wise reverses: pixel.hip.  Slab-produced gradients (split-K dW, bias partials, LayerNorm / head partials) are registered
+// for a grouped reduce per block; the rest is written directly.
+static int pixel_backward(afr_plan* p, hipStream_t s) {
+    const afr_config& c = p->cfg;
+    RTable rt;
+    rt.nseg = 0; rt.nblocks = 0; rt.adam = 0;
+    const int B = p->last_B, d = c.embed_dim, ff = c.fc_dim, T = c.out_h * c.out_w, C = c.n_fonts > 0 ? 2 : 1;
+    const long long rows = (long long)B * T;
+    const int ob = c.dtype == AFR_BF16 ? AFR_GEMM_OUT_BF16 : 0;
+    const int nbp = afr_pixel_bwd_blocks(rows);
+    float* du = (float*)(p->ws + p->o_u);
+    float* dh = (float*)(p->ws + p->o_dh);
+    void* dhT = c.dtype == AFR_BF16 ? (void*)(p->ws + p->o_dht) : (void*)dh;      // the GEMM-operand copy of dh (f32 mode: dh itself)
+    void *dfb = p->ws + p->o_df, *dn = p->ws + p->o_dn, *dq = p->ws + p->o_dq, *ctx = p->ws + p->o_ctx;
+    int rc;
+    {
+        float* hp = (float*)(p->ws + p->o_headp);
+        ProfScope ps(p, s, "pixel_head_bwd", 0.0, (double)rows * d * 12.0);
+        HIPCHK(afr_launch_pixel_head_bwd(c.dtype, du, (const float*)(p->ws + p->o_hf), p->P + p->px_lnfg, p->P + p->px_lnfb, p->P + p->px_wout, dh,
+                                         c.dtype == AFR_BF16 ? dhT : nullptr, hp, rows, d, c.ln_eps, s));
+        afr_rtable_add(rt, p->G + p->px_lnfg, hp, nbp, 4ll * d, d);
+        afr_rtable_add(rt, p->G + p->px_lnfb, hp + d, nbp, 4ll * d, d);
+        afr_rtable_add(rt, p->G + p->px_wout, hp + 2 * d, nbp, 4ll * d, d);
+        afr_rtable_add(rt, p->G + p->px_bout, hp + 3 * d, nbp, 4ll * d, 4);       // (element 0 is db_out; the 3 after it are zero: a 64-aligned tensor)
+    }
+    for (int l = c.n_hidden - 1; l >= 0; --l) {
+        const afr_plan::PixBlock& b = p->pix[l];
+        const afr_plan::PixSave& sv = p->pxs[l];
+        afr_plan::Layer* L5 = &p->pxl[(size_t)l * 5];                 // q, kv, out-proj, fc1, fc2
+        // ---- MLP:  h_out = h1 + fc2(relu(fc1(LN2(h1))))
+        if ((rc = run_dw(p, s, L5[4], dhT, p->ws + sv.f, (int)rows, rt))) return rc;
+        if ((rc = run_gemm(p, s, AFR_GEMM_B_KSTRIDED | AFR_GEMM_RELU_MASK | ob, dhT, weight_ptr(p, b.w2), dfb, nullptr, p->ws + sv.f, (int)rows, ff, d, d, ff, ff, ff, 1, 0))) return rc;
+        if ((rc = run_dw(p, s, L5[3], dfb, p->ws + sv.n2, (int)rows, rt))) return rc;
+        if ((rc = run_gemm(p, s, AFR_GEMM_B_KSTRIDED | ob, dfb, weight_ptr(p, b.w1), dn, nullptr, nullptr, (int)rows, d, ff, ff, d, d, 0, 1, 0))) return rc;
+        {
+            float* lp = (float*)(p->ws + sv.ln2p);
+            ProfScope ps(p, s, "pixel_ln_bwd", 0.0, (double)rows * d * (12.0 + 2.0 * p->act_bytes));
+            HIPCHK(afr_launch_pixel_ln_bwd(c.dtype, dn, (const float*)(p->ws + sv.h1), p->P + b.ln2g, dh, c.dtype == AFR_BF16 ? dhT : nullptr, lp, rows, d, c.ln_eps, s));
+            afr_rtable_add(rt, p->G + b.ln2g, lp, nbp, 2ll * d, d);
+            afr_rtable_add(rt, p->G + b.ln2b, lp + d, nbp, 2ll * d, d);
+        }
+        // ---- attention:  h1 = hin + out_proj(softmax(q k^T) v)
+        if ((rc = run_dw(p, s, L5[2], dhT, p->ws + sv.o, (int)rows, rt))) return rc;
+        if ((rc = run_gemm(p, s, AFR_GEMM_B_KSTRIDED | ob, dhT, weight_ptr(p, b.wo), dn, nullptr, nullptr, (int)rows, d, d, d, d, d, 0, 1, 0))) return rc;
+        const int chunk = afr_pixel_attn_chunk(T), chunks = (T + chunk - 1) / chunk;
+        float *dkvp = (float*)(p->ws + p->o_dkvp), *dkv = (float*)(p->ws + p->o_dkv);
+        {
+            ProfScope ps(p, s, "pixel_attn_bwd", 0.0, (double)rows * d * 3.0 * p->act_bytes);
+            HIPCHK(afr_launch_pixel_attn_bwd(c.dtype, dn, p->ws + sv.q, p->ws + sv.kv, dq, dkvp, B, T, d, C, s));
+        }
+        // dk | dv of every context token: the chunk slabs summed in chunk order (one chunk: the kernel's output is the sum)
+        if (chunks > 1) {
+            ProfScope ps(p, s, "reduce", 0.0, (double)B * 4 * d * 4.0 * (chunks + 1));
+            HIPCHK(afr_launch_reduce(dkv, dkvp, chunks, (long long)B * 4 * d, (long long)B * 4 * d, 1.f, 0, s));
+        }
+        // the GEMM operand [B*C][2d] in the activation dtype: row c of sample b = [dk_c | dv_c] (C = 1: the first 2d of the 4d)
+        void* dkvT = p->ws + p->o_dkvt;
+        HIPCHK(afr_launch_pixel_cast(c.dtype, dkvT, chunks > 1 ? dkv : dkvp, B, C * 2 * d, 4 * d, s));
+        if ((rc = run_dw(p, s, L5[0], dq, p->ws + sv.n1, (int)rows, rt))) return rc;
+        if ((rc = run_gemm(p, s, AFR_GEMM_B_KSTRIDED | ob, dq, weight_ptr(p, b.win), dn, nullptr, nullptr, (int)rows, d, d, d, d, d, 0, 1, 0))) return rc;
+        if ((rc = run_dw(p, s, L5[1], dkvT, ctx, B * C, rt))) return rc;
+        if ((rc = run_gemm(p, s, AFR_GEMM_B_KSTRIDED | ob, dkvT, weight_ptr(p, b.win + (int64_t)d * d), p->ws + p->o_dctxt, nullptr, nullptr, B * C, d, 2 * d, 2 * d, d, d, 0, 1, 0))) return rc;
+        HIPCHK(afr_launch_pixel_accum(c.dtype, (float*)(p->ws + p->o_dctx), p->ws + p->o_dctxt, (long long)B * C * d, l == c.n_hidden - 1, s));
+        {
+            float* lp = (float*)(p->ws + sv.ln1p);
+            ProfScope ps(p, s, "pixel_ln_bwd", 0.0, (double)rows * d * (12.0 + 2.0 * p->act_bytes));
+            HIPCHK(afr_launch_pixel_ln_bwd(c.dtype, dn, (const float*)(p->ws + sv.hin), p->P + b.ln1g, dh, c.dtype == AFR_BF16 ? dhT : nullptr, lp, rows, d, c.ln_eps, s));
+            afr_rtable_add(rt, p->G + b.ln1g, lp, nbp, 2ll * d, d);
+            afr_rtable_add(rt, p->G + b.ln1b, lp + d, nbp, 2ll * d, d);
+        }
+        // a block registers 14 slab sets (5 weights, 5 biases, 4 LayerNorm vectors; + the head's 4 with the last block): summed per
+        // block, since the grouped reduce takes 32 segments
+        if ((rc = run_reduce_group(p, s, rt))) return rc;
+        rt.nseg = 0; rt.nblocks = 0;
+    }
+    // positional table: the sum over the batch of the gradient of the residual stream's first value (model.py:140-141 idiom)
+    HIPCHK(afr_launch_reduce(p->G + p->px_pos, dh, B, (long long)T * d, (long long)T * d, 1.f, 0, s));
+    HIPCHK(afr_launch_pixel_ctx_bwd((const float*)(p->ws + p->o_dctx), p->last_x, p->last_font, B, d, c.vocab, c.n_fonts, p->G + p->px_emb,
+                                    p->px_font >= 0 ? p->G + p->px_font : nullptr, s));
+    return AFR_OK;
+}
+
 static int backward_stage_impl(afr_plan* p, int stage, int64_t* g_off, int64_t* g_len, hipStream_t s, RTable* shared_rt) {
     const afr_config& c = p->cfg;
     const int B = p->last_B, Pix = c.out_h * c.out_w;
@@ -916,6 +1039,12 @@ static int backward_stage_impl(afr_plan* p, int stage, int64_t* g_off, int64_t* 
     local_rt.nseg = 0; local_rt.nblocks = 0; local_rt.adam = 0;
     RTable& rt = shared_rt ? *shared_rt : local_rt;
     auto flush = [&]() -> int { return shared_rt ? AFR_OK : run_reduce_group(p, s, rt); };
+    if (c.kind == AFR_KIND_PIXEL) {        // one stage: the whole reverse pass (its slab reductions are flushed per block inside)
+        if ((rc = pixel_backward(p, s))) return rc;
+        if (g_off) *g_off = 0;
+        if (g_len) *g_len = p->total;
+        return AFR_OK;
+    }
     if (c.kind == AFR_KIND_SHEET) {
         const int Kz = c.max_length * c.fc_dim;
         void* z = p->ws + p->o_z;
@@ -1056,6 +1185,7 @@ static int backward_stage_impl(afr_plan* p, int stage, int64_t* g_off, int64_t* 
 
 extern "C" int afr_backward_stages(const afr_plan* p) {
     if (!p) return 0;
+    if (p->cfg.kind == AFR_KIND_PIXEL) return 1;
     return p->cfg.kind == AFR_KIND_SHEET ? 2 : (int)p->layers.size();
 }
 
@@ -1256,7 +1386,6 @@ extern "C" int afr_train_step(afr_plan* p, const int64_t* x, const int64_t* font
     if (tdtype != AFR_TARGET_U8 && tdtype != AFR_TARGET_F32) return fail(AFR_EINVAL, "bad target dtype");
     if (mean_elems <= 0) return fail(AFR_EINVAL, "mean_elems must be positive");
     if (!p || !p->P) return fail(AFR_ESTATE, "plan has no bound parameters");
-    if (p->cfg.kind == AFR_KIND_PIXEL) return fail(AFR_EUNSUPPORTED, "the pixel-token transformer has no training path yet (forward only)");
     DevGuard dg(p->device);
     if (p->fused1 && !(p->cfg.reserved & 4)) {
         // small glyph net: forward + loss + backward in ONE launch, then the grouped reduce (with AdamW when stepping here)
@@ -1280,7 +1409,7 @@ extern "C" int afr_train_step(afr_plan* p, const int64_t* x, const int64_t* font
         if (t < 1) return fail(AFR_EINVAL, "t starts at 1");
         return sheet_fused_step(p, (hipStream_t)stream, lr, b1, b2, eps, wd, t);
     }
-    if (do_step && p->M && p->V && !(p->cfg.reserved & 1)) {
+    if (do_step && p->M && p->V && !(p->cfg.reserved & 1) && p->cfg.kind != AFR_KIND_PIXEL) {
         if (t < 1) return fail(AFR_EINVAL, "t starts at 1");
         const int n = afr_backward_stages(p);
         RTable rt;

@@ -276,8 +276,20 @@ hipError_t afr_launch_glyph1_step(int dtype, const Glyph1Args& a, hipStream_t s)
 // per-pixel-token transformer (pixel.hip): the token-wise kernels of BASELINE configs[4]; forward only so far
 hipError_t afr_launch_pixel_ctx(int act_dtype, const float* emb, const float* femb, const int64_t* x, const int64_t* font, int B, int d,
                                 int vocab, int n_fonts, void* ctx, uint32_t* err, hipStream_t s);
-hipError_t afr_launch_pixel_add_ln(int act_dtype, float* h, const float* pos, const void* add, const float* g, const float* b, void* n,
+hipError_t afr_launch_pixel_add_ln(int act_dtype, const float* hin, float* h, const float* pos, const void* add, const float* g, const float* b, void* n,
                                    long long rows, int Tk, int d, float eps, hipStream_t s);
 hipError_t afr_launch_pixel_attn(int act_dtype, const void* q, const void* kv, void* o, long long rows, int Tk, int d, int heads, int C, hipStream_t s);
-hipError_t afr_launch_pixel_head(int act_dtype, float* h, const void* add, const float* g, const float* b, const float* w_out, const float* b_out,
+hipError_t afr_launch_pixel_head(int act_dtype, const float* hin, float* h, const void* add, const float* g, const float* b, const float* w_out, const float* b_out,
                                  float* u, float* y, long long rows, int d, float eps, hipStream_t s);
+int afr_pixel_bwd_blocks(long long rows);           // blocks (= partial slabs) of the head / LayerNorm backward kernels
+int afr_pixel_attn_chunk(int Tk);                   // tokens per attention-backward block
+hipError_t afr_launch_pixel_head_bwd(int act_dtype, const float* du, const float* hf, const float* g, const float* b, const float* w_out, float* dh,
+                                     void* dhT, float* part /*[blocks][4][d]: dgamma, dbeta, dw_out, db_out*/, long long rows, int d, float eps, hipStream_t s);
+hipError_t afr_launch_pixel_ln_bwd(int act_dtype, const void* dy, const float* hin, const float* g, float* dh, void* dhT, float* part /*[blocks][2][d]*/,
+                                   long long rows, int d, float eps, hipStream_t s);
+hipError_t afr_launch_pixel_attn_bwd(int act_dtype, const void* dO, const void* q, const void* kv, void* dq, float* dkv_part /*[chunks][B][2][2d]*/,
+                                     int B, int Tk, int d, int C, hipStream_t s);
+hipError_t afr_launch_pixel_ctx_bwd(const float* dctx, const int64_t* x, const int64_t* font, int B, int d, int vocab, int n_fonts, float* demb, float* dfont,
+                                    hipStream_t s);
+hipError_t afr_launch_pixel_accum(int act_dtype, float* acc, const void* src, long long n, int first, hipStream_t s);
+hipError_t afr_launch_pixel_cast(int act_dtype, void* dst, const float* src, long long rows, int w, int ld_src, hipStream_t s);

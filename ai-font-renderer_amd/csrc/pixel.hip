@@ -68,9 +68,9 @@ __global__ __launch_bounds__(256) void pixel_ctx_kernel(const float* __restrict_
 }
 // h = (first ? pos[t] : h) + (add ? add : 0);  n = LayerNorm(h) * g + b   -- rows = B * Tk tokens, one wave per row
 template <typename T>
-__global__ __launch_bounds__(256) void pixel_add_ln_kernel(float* __restrict__ h, const float* __restrict__ pos, const T* __restrict__ add,
-                                                           const float* __restrict__ g, const float* __restrict__ b, T* __restrict__ n,
-                                                           long long rows, int Tk, int d, float eps) {
+__global__ __launch_bounds__(256) void pixel_add_ln_kernel(const float* __restrict__ hin, float* __restrict__ h, const float* __restrict__ pos,
+                                                           const T* __restrict__ add, const float* __restrict__ g, const float* __restrict__ b,
+                                                           T* __restrict__ n, long long rows, int Tk, int d, float eps) {
     const int lane = threadIdx.x & 63;
     const int c0 = 8 * lane;
     const bool live = c0 < d;
@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256) void pixel_add_ln_kernel(float* __restrict__ h
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = 0.f;
         if (live) {
-            const float* src = pos ? pos + (size_t)(r % Tk) * d + c0 : h + (size_t)r * d + c0;
+            const float* src = pos ? pos + (size_t)(r % Tk) * d + c0 : hin + (size_t)r * d + c0;
             const float4 a0 = *reinterpret_cast<const float4*>(src), a1 = *reinterpret_cast<const float4*>(src + 4);
             v[0] = a0.x; v[1] = a0.y; v[2] = a0.z; v[3] = a0.w; v[4] = a1.x; v[5] = a1.y; v[6] = a1.z; v[7] = a1.w;
             if (add) {
@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256) void pixel_attn_kernel(const T* __restrict__ q
 }
 // h += add;  u = LayerNorm_f(h) . w_out + b_out;  y = clamp(u, 0, 1)      (model.py:152-156 idiom)
 template <typename T>
-__global__ __launch_bounds__(256) void pixel_head_kernel(float* __restrict__ h, const T* __restrict__ add, const float* __restrict__ g,
+__global__ __launch_bounds__(256) void pixel_head_kernel(const float* __restrict__ hin, float* __restrict__ h, const T* __restrict__ add, const float* __restrict__ g,
                                                          const float* __restrict__ b, const float* __restrict__ w_out, const float* __restrict__ b_out,
                                                          float* __restrict__ u, float* __restrict__ y, long long rows, int d, float eps) {
     const int lane = threadIdx.x & 63, c0 = 8 * lane;
@@ -152,7 +152,7 @@ __global__ __launch_bounds__(256) void pixel_head_kernel(float* __restrict__ h, 
         float v[8], av[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = av[j] = 0.f;
-        if (live) { ld8v(h + (size_t)r * d + c0, v); ld8v(add + (size_t)r * d + c0, av); }
+        if (live) { ld8v(hin + (size_t)r * d + c0, v); ld8v(add + (size_t)r * d + c0, av); }
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] += av[j];
         if (live) {
@@ -186,11 +186,11 @@ hipError_t afr_launch_pixel_ctx(int act_dtype, const float* emb, const float* fe
     else hipLaunchKernelGGL(pixel_ctx_kernel<float>, dim3(grid), dim3(256), 0, s, emb, femb, x, font, B, d, vocab, n_fonts, (float*)ctx, err);
     return hipGetLastError();
 }
-hipError_t afr_launch_pixel_add_ln(int act_dtype, float* h, const float* pos, const void* add, const float* g, const float* b, void* n,
+hipError_t afr_launch_pixel_add_ln(int act_dtype, const float* hin, float* h, const float* pos, const void* add, const float* g, const float* b, void* n,
                                    long long rows, int Tk, int d, float eps, hipStream_t s) {
     if (d > 512 || (d & 7)) return hipErrorInvalidValue;
-    if (act_dtype == AFR_BF16) hipLaunchKernelGGL(pixel_add_ln_kernel<bf16_t>, dim3(pix_grid(rows)), dim3(256), 0, s, h, pos, (const bf16_t*)add, g, b, (bf16_t*)n, rows, Tk, d, eps);
-    else hipLaunchKernelGGL(pixel_add_ln_kernel<float>, dim3(pix_grid(rows)), dim3(256), 0, s, h, pos, (const float*)add, g, b, (float*)n, rows, Tk, d, eps);
+    if (act_dtype == AFR_BF16) hipLaunchKernelGGL(pixel_add_ln_kernel<bf16_t>, dim3(pix_grid(rows)), dim3(256), 0, s, hin, h, pos, (const bf16_t*)add, g, b, (bf16_t*)n, rows, Tk, d, eps);
+    else hipLaunchKernelGGL(pixel_add_ln_kernel<float>, dim3(pix_grid(rows)), dim3(256), 0, s, hin, h, pos, (const float*)add, g, b, (float*)n, rows, Tk, d, eps);
     return hipGetLastError();
 }
 hipError_t afr_launch_pixel_attn(int act_dtype, const void* q, const void* kv, void* o, long long rows, int Tk, int d, int heads, int C, hipStream_t s) {
@@ -199,10 +199,260 @@ hipError_t afr_launch_pixel_attn(int act_dtype, const void* q, const void* kv, v
     else hipLaunchKernelGGL(pixel_attn_kernel<float>, dim3(pix_grid(rows)), dim3(256), 0, s, (const float*)q, (const float*)kv, (float*)o, rows, Tk, d, C);
     return hipGetLastError();
 }
-hipError_t afr_launch_pixel_head(int act_dtype, float* h, const void* add, const float* g, const float* b, const float* w_out, const float* b_out,
+hipError_t afr_launch_pixel_head(int act_dtype, const float* hin, float* h, const void* add, const float* g, const float* b, const float* w_out, const float* b_out,
                                  float* u, float* y, long long rows, int d, float eps, hipStream_t s) {
     if (d > 512 || (d & 7)) return hipErrorInvalidValue;
-    if (act_dtype == AFR_BF16) hipLaunchKernelGGL(pixel_head_kernel<bf16_t>, dim3(pix_grid(rows)), dim3(256), 0, s, h, (const bf16_t*)add, g, b, w_out, b_out, u, y, rows, d, eps);
-    else hipLaunchKernelGGL(pixel_head_kernel<float>, dim3(pix_grid(rows)), dim3(256), 0, s, h, (const float*)add, g, b, w_out, b_out, u, y, rows, d, eps);
+    if (act_dtype == AFR_BF16) hipLaunchKernelGGL(pixel_head_kernel<bf16_t>, dim3(pix_grid(rows)), dim3(256), 0, s, hin, h, (const bf16_t*)add, g, b, w_out, b_out, u, y, rows, d, eps);
+    else hipLaunchKernelGGL(pixel_head_kernel<float>, dim3(pix_grid(rows)), dim3(256), 0, s, hin, h, (const float*)add, g, b, w_out, b_out, u, y, rows, d, eps);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------- backward (round 3)
+// Every kernel below walks token rows one wave per row like its forward twin and leaves its parameter-gradient partial sums
+// as ONE slab per block ([nblk][...], block order), which the grouped reduce adds in fixed order: bitwise reproducible.
+namespace {
+constexpr int PIX_BWD_BLOCKS = 512;        // blocks of the backward token kernels = slabs per LayerNorm / head gradient
+// sum the 4 waves' per-lane partials (8 channels each, K arrays) through LDS and store wave 0's total: slab[k][d]
+template <int K>
+__device__ __forceinline__ void block_store_partials(float (&acc)[K][8], float* slab, int d, int c0, bool live, float* sh) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        if (wave > 0) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) sh[((wave - 1) * 64 + lane) * 8 + j] = acc[k][j];
+        }
+        __syncthreads();
+        if (wave == 0 && live) {
+            float out[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) out[j] = ((acc[k][j] + sh[(0 * 64 + lane) * 8 + j]) + sh[(1 * 64 + lane) * 8 + j]) + sh[(2 * 64 + lane) * 8 + j];
+            *reinterpret_cast<float4*>(slab + (size_t)k * d + c0) = make_float4(out[0], out[1], out[2], out[3]);
+            *reinterpret_cast<float4*>(slab + (size_t)k * d + c0 + 4) = make_float4(out[4], out[5], out[6], out[7]);
+        }
+        __syncthreads();
+    }
+}
+// LayerNorm backward of one row: x (pre-norm input), dy (gradient of the affine output) -> dx; accumulates dgamma, dbeta
+__device__ __forceinline__ void row_ln_bwd(const float (&x)[8], const float (&dy)[8], const float* __restrict__ g, int c0, int d, float eps, bool live,
+                                           float (&dx)[8], float (&dg)[8], float (&db)[8]) {
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += live ? x[j] : 0.f;
+    const float mu = wave_sum(s) / (float)d;
+    float xc[8], q = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { xc[j] = x[j] - mu; q = live ? fmaf(xc[j], xc[j], q) : q; }
+    const float rstd = rsqrtf(wave_sum(q) / (float)d + eps);
+    float gg[8], m1 = 0.f, m2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float xh = xc[j] * rstd;
+        xc[j] = xh;
+        gg[j] = live ? dy[j] * g[c0 + j] : 0.f;
+        m1 += gg[j]; m2 = fmaf(gg[j], xh, m2);
+        if (live) { dg[j] = fmaf(dy[j], xh, dg[j]); db[j] += dy[j]; }
+    }
+    m1 = wave_sum(m1) / (float)d; m2 = wave_sum(m2) / (float)d;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) dx[j] = (gg[j] - m1 - xc[j] * m2) * rstd;
+}
+}  // namespace
+// head backward: du [rows] -> dh = LN_f-backward(du * w_out); partials [nblk][4][d]: dgamma_f, dbeta_f, dw_out, (db_out in [3][0])
+template <typename T>
+__global__ __launch_bounds__(256) void pixel_head_bwd_kernel(const float* __restrict__ du, const float* __restrict__ hf, const float* __restrict__ g,
+                                                             const float* __restrict__ bta, const float* __restrict__ w_out, float* __restrict__ dh,
+                                                             T* __restrict__ dhT, float* __restrict__ part, long long rows, int d, float eps) {
+    __shared__ float sh[3 * 64 * 8];
+    const int lane = threadIdx.x & 63, c0 = 8 * lane;
+    const bool live = c0 < d;
+    float acc[4][8];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[k][j] = 0.f;
+    for (long long r = blockIdx.x * 4ll + (threadIdx.x >> 6); r < rows; r += (long long)gridDim.x * 4) {
+        float x[8], dy[8], dx[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] = 0.f;
+        if (live) ld8v(hf + (size_t)r * d + c0, x);
+        const float dur = du[r];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dy[j] = live ? dur * w_out[c0 + j] : 0.f;
+        // nf = LN_f(hf) for dw_out: recomputed (xhat * g + b)
+        float xs[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) xs[j] = x[j];
+        row_layernorm(xs, g, bta, c0, d, eps, live);
+        row_ln_bwd(x, dy, g, c0, d, eps, live, dx, acc[0], acc[1]);
+        if (live) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[2][j] = fmaf(dur, xs[j], acc[2][j]);
+            if (lane == 0) acc[3][0] += dur;
+            float* o = dh + (size_t)r * d + c0;
+            *reinterpret_cast<float4*>(o) = make_float4(dx[0], dx[1], dx[2], dx[3]);
+            *reinterpret_cast<float4*>(o + 4) = make_float4(dx[4], dx[5], dx[6], dx[7]);
+            if (dhT) st8v(dhT + (size_t)r * d + c0, dx);
+        }
+    }
+    block_store_partials<4>(acc, part + (size_t)blockIdx.x * 4 * d, d, c0, live, sh);
+}
+// LayerNorm backward with the residual: dh <- dh + LN-backward(dy; x = hin);  partials [nblk][2][d]: dgamma, dbeta
+template <typename T>
+__global__ __launch_bounds__(256) void pixel_ln_bwd_kernel(const T* __restrict__ dyT, const float* __restrict__ hin, const float* __restrict__ g,
+                                                           float* __restrict__ dh, T* __restrict__ dhT, float* __restrict__ part, long long rows, int d,
+                                                           float eps) {
+    __shared__ float sh[3 * 64 * 8];
+    const int lane = threadIdx.x & 63, c0 = 8 * lane;
+    const bool live = c0 < d;
+    float acc[2][8];
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[k][j] = 0.f;
+    for (long long r = blockIdx.x * 4ll + (threadIdx.x >> 6); r < rows; r += (long long)gridDim.x * 4) {
+        float x[8], dy[8], dx[8], res[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] = dy[j] = res[j] = 0.f;
+        if (live) { ld8v(hin + (size_t)r * d + c0, x); ld8v(dyT + (size_t)r * d + c0, dy); ld8v(dh + (size_t)r * d + c0, res); }
+        row_ln_bwd(x, dy, g, c0, d, eps, live, dx, acc[0], acc[1]);
+        if (live) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) res[j] += dx[j];
+            st8v(dh + (size_t)r * d + c0, res);
+            if (dhT) st8v(dhT + (size_t)r * d + c0, res);
+        }
+    }
+    block_store_partials<2>(acc, part + (size_t)blockIdx.x * 2 * d, d, c0, live, sh);
+}
+// cross-attention backward (C <= 2 keys): do, q, kv -> dq [rows][d]; dk | dv of the sample's context tokens summed over a
+// chunk of its tokens: dkv_part [chunks][B][2][2 d] -- one slab per chunk, so ONE slab reduce over the chunks finishes every
+// sample's sums (block = (sample, chunk); the 4 waves' sums are added in wave order)
+template <typename T>
+__global__ __launch_bounds__(256) void pixel_attn_bwd_kernel(const T* __restrict__ dO, const T* __restrict__ q, const T* __restrict__ kv, T* __restrict__ dq,
+                                                             float* __restrict__ dkv_part, int Tk, int chunk, int d, int C) {
+    __shared__ float sh[3 * 64 * 8];
+    const int lane = threadIdx.x & 63, c0 = 8 * lane, wave = threadIdx.x >> 6;
+    const bool live = c0 < d;
+    const int chunks = (Tk + chunk - 1) / chunk;
+    const int b = blockIdx.x / chunks, ch = blockIdx.x - b * chunks;
+    float kk[2][8], vv[2][8], acc[4][8];               // acc: dk0, dv0, dk1, dv1
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) kk[c][j] = vv[c][j] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[k][j] = 0.f;
+    for (int c = 0; c < C; ++c)
+        if (live) { const T* kr = kv + ((size_t)b * C + c) * 2 * d; ld8v(kr + c0, kk[c]); ld8v(kr + d + c0, vv[c]); }
+    const int t1 = min(Tk, (ch + 1) * chunk);
+    for (int t = ch * chunk + wave; t < t1; t += 4) {
+        const size_t r = (size_t)b * Tk + t;
+        float qv[8], dov[8], s[2] = {0.f, 0.f}, dp[2] = {0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) qv[j] = dov[j] = 0.f;
+        if (live) { ld8v(q + r * d + c0, qv); ld8v(dO + r * d + c0, dov); }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) qv[j] *= 0.125f;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            float a = 0.f, e = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { a = fmaf(qv[j], kk[c][j], a); e = fmaf(dov[j], vv[c][j], e); }
+            a += __shfl_xor(a, 1, 64); a += __shfl_xor(a, 2, 64); a += __shfl_xor(a, 4, 64);
+            e += __shfl_xor(e, 1, 64); e += __shfl_xor(e, 2, 64); e += __shfl_xor(e, 4, 64);
+            s[c] = a; dp[c] = e;
+        }
+        float p0 = 1.f, p1 = 0.f;
+        if (C == 2) {
+            const float m = fmaxf(s[0], s[1]);
+            const float e0 = __expf(s[0] - m), e1 = __expf(s[1] - m), inv = 1.f / (e0 + e1);
+            p0 = e0 * inv; p1 = e1 * inv;
+        }
+        const float dot = p0 * dp[0] + p1 * dp[1];
+        const float ds0 = p0 * (dp[0] - dot), ds1 = p1 * (dp[1] - dot);       // softmax backward (zero when C == 1)
+        float dqv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            dqv[j] = (ds0 * kk[0][j] + ds1 * kk[1][j]) * 0.125f;
+            acc[0][j] = fmaf(ds0, qv[j], acc[0][j]); acc[1][j] = fmaf(p0, dov[j], acc[1][j]);
+            acc[2][j] = fmaf(ds1, qv[j], acc[2][j]); acc[3][j] = fmaf(p1, dov[j], acc[3][j]);
+        }
+        if (live) st8v(dq + r * d + c0, dqv);
+    }
+    // partial layout [C][2 d] = [dk_c | dv_c]: rows (k-arrays) 0..3 = dk0, dv0, dk1, dv1 are consecutive d-vectors
+    block_store_partials<4>(acc, dkv_part + ((size_t)ch * (gridDim.x / chunks) + b) * 4 * d, d, c0, live, sh);
+}
+// dEmb[v] = sum over glyphs b with x_b == v of dctx[b][0];  dFont[f] likewise with dctx[b][1]   (embedding_dense_backward)
+__global__ __launch_bounds__(256) void pixel_ctx_bwd_kernel(const float* __restrict__ dctx, const int64_t* __restrict__ x, const int64_t* __restrict__ font,
+                                                            int B, int d, int vocab, int n_fonts, float* __restrict__ demb, float* __restrict__ dfont) {
+    const int row = blockIdx.x, C = n_fonts > 0 ? 2 : 1;
+    const bool is_font = row >= vocab;
+    const int target = is_font ? row - vocab : row;
+    for (int k = threadIdx.x; k < d; k += 256) {
+        float a = 0.f;
+        for (int b = 0; b < B; ++b) {
+            long long id = is_font ? font[b] : x[b];
+            id = min(max(id, 0ll), (long long)(is_font ? n_fonts : vocab) - 1);
+            if ((int)id == target) a += dctx[((size_t)b * C + (is_font ? 1 : 0)) * d + k];
+        }
+        (is_font ? dfont : demb)[(size_t)target * d + k] = a;
+    }
+}
+// acc (f32) += src (T)   /  acc = src when first
+template <typename T>
+__global__ __launch_bounds__(256) void pixel_accum_kernel(float* __restrict__ acc, const T* __restrict__ src, long long n, int first) {
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256) acc[i] = (first ? 0.f : acc[i]) + (float)src[i];
+}
+// dst (T) [rows][w] = src (f32) [rows][ld_src], the first w columns of every row
+template <typename T>
+__global__ __launch_bounds__(256) void pixel_cast_kernel(T* __restrict__ dst, const float* __restrict__ src, long long rows, int w, int ld_src) {
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < rows * w; i += (long long)gridDim.x * 256) {
+        const long long r = i / w;
+        dst[i] = pcvt<T>(src[r * ld_src + (i - r * w)]);
+    }
+}
+int afr_pixel_bwd_blocks(long long rows) { long long g = (rows + 3) / 4; return (int)(g < 1 ? 1 : (g > PIX_BWD_BLOCKS ? PIX_BWD_BLOCKS : g)); }
+hipError_t afr_launch_pixel_head_bwd(int act_dtype, const float* du, const float* hf, const float* g, const float* b, const float* w_out, float* dh,
+                                     void* dhT, float* part, long long rows, int d, float eps, hipStream_t s) {
+    const int grid = afr_pixel_bwd_blocks(rows);
+    if (act_dtype == AFR_BF16) hipLaunchKernelGGL(pixel_head_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, du, hf, g, b, w_out, dh, (bf16_t*)dhT, part, rows, d, eps);
+    else hipLaunchKernelGGL(pixel_head_bwd_kernel<float>, dim3(grid), dim3(256), 0, s, du, hf, g, b, w_out, dh, (float*)nullptr, part, rows, d, eps);
+    return hipGetLastError();
+}
+hipError_t afr_launch_pixel_ln_bwd(int act_dtype, const void* dy, const float* hin, const float* g, float* dh, void* dhT, float* part, long long rows,
+                                   int d, float eps, hipStream_t s) {
+    const int grid = afr_pixel_bwd_blocks(rows);
+    if (act_dtype == AFR_BF16) hipLaunchKernelGGL(pixel_ln_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)dy, hin, g, dh, (bf16_t*)dhT, part, rows, d, eps);
+    else hipLaunchKernelGGL(pixel_ln_bwd_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)dy, hin, g, dh, (float*)nullptr, part, rows, d, eps);
+    return hipGetLastError();
+}
+int afr_pixel_attn_chunk(int Tk) { return Tk <= 256 ? Tk : 256; }
+hipError_t afr_launch_pixel_attn_bwd(int act_dtype, const void* dO, const void* q, const void* kv, void* dq, float* dkv_part, int B, int Tk, int d, int C,
+                                     hipStream_t s) {
+    const int chunk = afr_pixel_attn_chunk(Tk), chunks = (Tk + chunk - 1) / chunk;
+    if (act_dtype == AFR_BF16) hipLaunchKernelGGL(pixel_attn_bwd_kernel<bf16_t>, dim3(B * chunks), dim3(256), 0, s, (const bf16_t*)dO, (const bf16_t*)q, (const bf16_t*)kv, (bf16_t*)dq, dkv_part, Tk, chunk, d, C);
+    else hipLaunchKernelGGL(pixel_attn_bwd_kernel<float>, dim3(B * chunks), dim3(256), 0, s, (const float*)dO, (const float*)q, (const float*)kv, (float*)dq, dkv_part, Tk, chunk, d, C);
+    return hipGetLastError();
+}
+hipError_t afr_launch_pixel_ctx_bwd(const float* dctx, const int64_t* x, const int64_t* font, int B, int d, int vocab, int n_fonts, float* demb, float* dfont,
+                                    hipStream_t s) {
+    hipLaunchKernelGGL(pixel_ctx_bwd_kernel, dim3(vocab + (n_fonts > 0 ? n_fonts : 0)), dim3(256), 0, s, dctx, x, font, B, d, vocab, n_fonts, demb, dfont);
+    return hipGetLastError();
+}
+hipError_t afr_launch_pixel_accum(int act_dtype, float* acc, const void* src, long long n, int first, hipStream_t s) {
+    const int grid = (int)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256);
+    if (act_dtype == AFR_BF16) hipLaunchKernelGGL(pixel_accum_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, acc, (const bf16_t*)src, n, first);
+    else hipLaunchKernelGGL(pixel_accum_kernel<float>, dim3(grid), dim3(256), 0, s, acc, (const float*)src, n, first);
+    return hipGetLastError();
+}
+hipError_t afr_launch_pixel_cast(int act_dtype, void* dst, const float* src, long long rows, int w, int ld_src, hipStream_t s) {
+    const long long n = rows * w;
+    const int grid = (int)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256);
+    if (act_dtype == AFR_BF16) hipLaunchKernelGGL(pixel_cast_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (bf16_t*)dst, src, rows, w, ld_src);
+    else hipLaunchKernelGGL(pixel_cast_kernel<float>, dim3(grid), dim3(256), 0, s, (float*)dst, src, rows, w, ld_src);
     return hipGetLastError();
 }
