@@ -273,7 +273,7 @@ size_t afr_glyph1_lds_bytes(int dtype, int E, int N1, int P, int table_rows);
 hipError_t afr_launch_transpose_bf16(const float* W, bf16_t* WT, int N, int K, hipStream_t s);
 hipError_t afr_launch_glyph1_step(int dtype, const Glyph1Args& a, hipStream_t s);
 
-// per-pixel-token transformer (pixel.hip): the token-wise kernels of BASELINE configs[4]; forward only so far
+// per-pixel-token transformer (pixel.hip): the token-wise kernels of BASELINE configs[4], forward and backward
 hipError_t afr_launch_pixel_ctx(int act_dtype, const float* emb, const float* femb, const int64_t* x, const int64_t* font, int B, int d,
                                 int vocab, int n_fonts, void* ctx, uint32_t* err, hipStream_t s);
 hipError_t afr_launch_pixel_add_ln(int act_dtype, const float* hin, float* h, const float* pos, const void* add, const float* g, const float* b, void* n,

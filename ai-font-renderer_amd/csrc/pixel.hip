@@ -1,7 +1,7 @@
 // pixel.hip -- the token-wise (non-GEMM) kernels of the per-pixel-token transformer, BASELINE configs[4] as DESIGN.md 8 defines
 // it (config.PixelConfig; oracle.pixel_forward): context gather, positional initialisation, residual-add + LayerNorm,
 // cross-attention of a pixel token to the glyph's <= 2 context tokens, and the LayerNorm + Linear(d -> 1) + clamp head.
-// The Linear layers run on the GEMM kernels of gemm.hip.  FORWARD ONLY so far (no counterpart in the reference: SURVEY 8 f5;
+// The Linear layers run on the GEMM kernels of gemm.hip.  Backward twins below (no counterpart in the reference: SURVEY 8 f5;
 // the layer idioms are model.py:136,140-145,148,152-156).  One wave per token row, 8 channels per lane: d_model <= 512,
 // a multiple of 64 x ... (checked by the launcher); the residual stream h stays float32, GEMM operands take the plan's
 // activation dtype T.

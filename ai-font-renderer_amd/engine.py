@@ -47,7 +47,7 @@ def make_afr_config(cfg, dtype, max_batch, seed=42, rank=0, flags=0):
             c.hidden[i] = h
         c.n_fonts = cfg.n_fonts
     elif isinstance(cfg, PixelConfig):
-        c.kind = _lib.AFR_KIND_PIXEL                 # BASELINE configs[4]: forward only so far (include/afr.h)
+        c.kind = _lib.AFR_KIND_PIXEL                 # BASELINE configs[4] (include/afr.h)
         c.embed_dim = cfg.d_model
         c.out_h, c.out_w = cfg.out_h, cfg.out_w
         c.heads, c.fc_dim, c.n_hidden, c.n_fonts, c.ln_eps = cfg.heads, cfg.ff_dim, cfg.layers, cfg.n_fonts, cfg.ln_eps

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Forward throughput of BASELINE configs[4]'s model (config.C5: 64x64 pixel tokens, d_model 512, 4 blocks) through
-the C ABI -- the only path this kind has so far (no backward yet), so this is NOT the training metric bench.py reports.
+the C ABI -- forward only (the training step: tools/c5_step_bench.py).
   python tools/c5_forward_bench.py [batch=32] [dtype=bf16]"""
 import os
 import sys
