@@ -103,7 +103,7 @@ struct afr_plan {
     struct PixBlock { int64_t ln1g, ln1b, win, bin, wo, bo, ln2g, ln2b, w1, b1, w2, b2; };
     std::vector<PixBlock> pix;
     int64_t px_pos = 0, px_emb = 0, px_font = -1, px_lnfg = 0, px_lnfb = 0, px_wout = 0, px_bout = 0;
-    struct PixSave { size_t hin, h1, n1, q, o, n2, kv, f, ln1p, ln2p; };      // per block: what its backward needs + its LayerNorm partial slabs
+    struct PixSave { size_t hin, h1, n1, q, o, n2, kv, f, ln1p, ln2p, fbits; };      // per block: what its backward needs + its LayerNorm partial slabs
     std::vector<PixSave> pxs;
     size_t o_ctx = 0, o_a = 0, o_hf = 0, o_dh = 0, o_dht = 0, o_df = 0, o_dn = 0, o_dq = 0, o_dkvp = 0, o_dkv = 0, o_dkvt = 0, o_dctxt = 0,
            o_dctx = 0, o_headp = 0;
@@ -351,6 +351,7 @@ extern "C" int afr_plan_create(const afr_config* c, afr_plan** out) {
             sv.hin = carve(rows * d * sizeof(float)); sv.h1 = carve(rows * d * sizeof(float));
             sv.n1 = carve(rows * d * ab); sv.q = carve(rows * d * ab); sv.o = carve(rows * d * ab); sv.n2 = carve(rows * d * ab);
             sv.kv = carve(B * C * 2 * d * ab); sv.f = carve(rows * ff * ab);
+            sv.fbits = c->dtype == AFR_BF16 ? carve(rows * (size_t)(ff / 8)) : 0;      // ReLU gate of F, one byte per 8 columns (bf16 mode)
             sv.ln1p = carve(nbp * 2 * d * sizeof(float)); sv.ln2p = carve(nbp * 2 * d * sizeof(float));
             p->pxs.push_back(sv);
             const afr_plan::PixBlock& b = p->pix[l];
@@ -829,7 +830,11 @@ static int forward_impl(afr_plan* p, const int64_t* x, const int64_t* font, int 
                 ProfScope ps(p, s, "pixel_add_ln", 0.0, (double)rows * d * (8.0 + 2.0 * p->act_bytes));
                 HIPCHK(afr_launch_pixel_add_ln(c.dtype, hin, h1, nullptr, a, p->P + b.ln2g, p->P + b.ln2b, n2, rows, T, d, c.ln_eps, s));
             }
-            if ((rc = run_gemm(p, s, AFR_GEMM_BIAS | AFR_GEMM_RELU | ob, n2, weight_ptr(p, b.w1), f, p->P + b.b1, nullptr, (int)rows, ff, d, d, d, ff, 0, 1, 0))) return rc;
+            // (bf16 mode: the epilogue also leaves the ReLU gate of the stored values as bits for the backward's input-gradient product)
+            RowMaps rmf{nullptr, nullptr, nullptr};
+            if (sv.fbits) { rmf.mask_out = (unsigned char*)(p->ws + sv.fbits); rmf.ldmask = ff / 8; }
+            if ((rc = run_gemm(p, s, AFR_GEMM_BIAS | AFR_GEMM_RELU | ob, n2, weight_ptr(p, b.w1), f, p->P + b.b1, nullptr, (int)rows, ff, d, d, d, ff, 0, 1, 0,
+                               nullptr, 0, nullptr, nullptr, nullptr, sv.fbits ? &rmf : nullptr))) return rc;
             if ((rc = run_gemm(p, s, AFR_GEMM_BIAS | ob, f, weight_ptr(p, b.w2), a, p->P + b.b2, nullptr, (int)rows, d, ff, ff, ff, d, 0, 1, 0))) return rc;
         }
         {
@@ -976,7 +981,10 @@ static int pixel_backward(afr_plan* p, hipStream_t s) {
         afr_plan::Layer* L5 = &p->pxl[(size_t)l * 5];                 // q, kv, out-proj, fc1, fc2
         // ---- MLP:  h_out = h1 + fc2(relu(fc1(LN2(h1))))
         if ((rc = run_dw(p, s, L5[4], dhT, p->ws + sv.f, (int)rows, rt))) return rc;
-        if ((rc = run_gemm(p, s, AFR_GEMM_B_KSTRIDED | AFR_GEMM_RELU_MASK | ob, dhT, weight_ptr(p, b.w2), dfb, nullptr, p->ws + sv.f, (int)rows, ff, d, d, ff, ff, ff, 1, 0))) return rc;
+        RowMaps rmf{nullptr, nullptr, nullptr};
+        if (sv.fbits) { rmf.mask_in = (const unsigned char*)(p->ws + sv.fbits); rmf.ldmask = ff / 8; }
+        if ((rc = run_gemm(p, s, AFR_GEMM_B_KSTRIDED | AFR_GEMM_RELU_MASK | ob, dhT, weight_ptr(p, b.w2), dfb, nullptr, p->ws + sv.f, (int)rows, ff, d, d, ff, ff, ff, 1, 0,
+                           nullptr, 0, nullptr, nullptr, nullptr, sv.fbits ? &rmf : nullptr))) return rc;
         if ((rc = run_dw(p, s, L5[3], dfb, p->ws + sv.n2, (int)rows, rt))) return rc;
         if ((rc = run_gemm(p, s, AFR_GEMM_B_KSTRIDED | ob, dfb, weight_ptr(p, b.w1), dn, nullptr, nullptr, (int)rows, d, ff, ff, d, d, 0, 1, 0))) return rc;
         {

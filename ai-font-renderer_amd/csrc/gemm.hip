@@ -353,32 +353,61 @@ __device__ unsigned long long* g_gemm_stamps = nullptr;
 #endif
 // The epilogue of one wave's 64x64 f32 accumulator tile whose top-left element is (mb, nb0) of the product; Wt = the
 // wave's own 16 KiB of LDS.  Shared by the 256x128 / 128x128 kernels (one call) and the 256x256 kernel (two calls).
-template <int ALAY, int BLAY, int WM, bool SCALE = false>      // SCALE: the accumulators are multiplied by p.out_scale first (fp8 per-tensor scales)
+template <int ALAY, int BLAY, int WM, bool SCALE = false, bool EARLYB_ = true>      // SCALE: the accumulators are multiplied by p.out_scale first (fp8 per-tensor scales)
 __device__ __forceinline__ void wave_epilogue(const GemmParams& p, const f32x4 (&acc)[4][4], const int mb, const int nb0, const int z,
                                               float* Wt, const int lane, float& lsum, const float* lut255 = nullptr) {
     // Epilogue through LDS: the MFMA accumulators hold 4 consecutive n of 16 different rows per lane-group, which as
     // direct stores would be 32-byte pieces.  Each wave parks its 64x64 f32 tile in its own 16 KiB of LDS (16-B chunks
     // XOR-swizzled by row: conflict-free both ways) and streams it out row-contiguous: 8 lanes x 8 values = one 64-col
     // row, so stores (and the aux / target loads of the fused tails) are whole 128-B / 256-B row segments.
+    // bias / ReLU in the row pass: the forward layout only (what the engine's Linear layers use); the other layouts, where the
+    // op-level API alone can ask for them, keep the per-fragment form and carry no extra code in their row passes
+    constexpr bool EARLYB = EARLYB_ && ALAY == 0 && BLAY == 0;
     const int flags = p.flags;
     const bool out_bf16 = flags & AFR_GEMM_OUT_BF16;
     const bool mse = p.mse_target != nullptr;
+    const int c8 = lane & 7;
+    const int n = nb0 + 8 * c8;
+    const bool ncol = n < p.N;
+    // The bias is added (and the ReLU taken) in the row-contiguous pass below, where a lane owns the same 8 (bf16 output) or
+    // 4 (f32 output) columns of every row: its few bias values are requested HERE, before the accumulators are parked, so the
+    // load's latency (2 us per tile on the K = 512 products of the pixel transformer when it was taken per accumulator
+    // fragment at this point) passes under the LDS round trip.  Same f32 additions, same results.
+    // (EARLYB = false: the 256x256 body, which sits at the register limit with its other accumulator half still live here, adds
+    // the bias per accumulator fragment while parking, as every kernel did before)
+    float bia[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    auto load_bias = [&]() {
+        if (!(flags & AFR_GEMM_BIAS)) return;
+        if (out_bf16) {
+            if (ncol) {
+                const float4 b0 = *reinterpret_cast<const float4*>(p.bias + n), b1 = *reinterpret_cast<const float4*>(p.bias + n + 4);
+                bia[0] = b0.x; bia[1] = b0.y; bia[2] = b0.z; bia[3] = b0.w; bia[4] = b1.x; bia[5] = b1.y; bia[6] = b1.z; bia[7] = b1.w;
+            }
+        } else if (nb0 + 4 * (lane & 15) < p.N) {
+            const float4 b0 = *reinterpret_cast<const float4*>(p.bias + nb0 + 4 * (lane & 15));
+            bia[0] = b0.x; bia[1] = b0.y; bia[2] = b0.z; bia[3] = b0.w;
+        }
+    };
+    if (EARLYB) load_bias();
+    const bool relu = EARLYB && (flags & AFR_GEMM_RELU);
+    const bool rowbias = EARLYB && (flags & AFR_GEMM_BIAS);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int ml = 16 * i + (lane & 15);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int nl = 16 * j + 4 * (lane >> 4);
-            const int n = nb0 + nl;
             f32x4 v = acc[i][j];
             if (SCALE) v *= p.out_scale;
-            if ((flags & AFR_GEMM_BIAS) && n < p.N) {
-                const float4 bb = *reinterpret_cast<const float4*>(p.bias + n);
-                v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
-            }
-            if (flags & AFR_GEMM_RELU) {
+            if (!EARLYB) {
+                if ((flags & AFR_GEMM_BIAS) && nb0 + nl < p.N) {
+                    const float4 bb = *reinterpret_cast<const float4*>(p.bias + nb0 + nl);
+                    v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
+                }
+                if (flags & AFR_GEMM_RELU) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+                    for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+                }
             }
             *reinterpret_cast<f32x4*>(Wt + ml * 64 + (((nl >> 2) ^ (ml & 15)) << 2)) = v;
         }
@@ -387,9 +416,6 @@ __device__ __forceinline__ void wave_epilogue(const GemmParams& p, const f32x4 (
     bf16_t* Cb = reinterpret_cast<bf16_t*>(p.C);
     const bf16_t* aux = reinterpret_cast<const bf16_t*>(p.aux);
     const float g2 = 2.f * p.mse_inv_n;
-    const int c8 = lane & 7;
-    const int n = nb0 + 8 * c8;
-    const bool ncol = n < p.N;
     const bool relu_mask = flags & AFR_GEMM_RELU_MASK;
     // the tails' global operands (aux for the ReLU mask, targets for the fused loss) are fetched for all 8 row passes
     // up front: one memory latency instead of eight serial ones
@@ -446,6 +472,8 @@ __device__ __forceinline__ void wave_epilogue(const GemmParams& p, const f32x4 (
             const int rl = ps * 4 + (lane >> 4);
             if (adam && ps + ADF - 1 < 16) load_f(ps + ADF - 1, (ps + ADF - 1) % ADF);
             f32x4 g = *reinterpret_cast<const f32x4*>(Wt + rl * 64 + ((c4 ^ (rl & 15)) << 2));
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { g[r] = rowbias ? g[r] + bia[r] : g[r]; g[r] = relu ? fmaxf(g[r], 0.f) : g[r]; }
             const int m = mb + rl;
             if (m >= p.M || !okc) continue;
             const size_t wi = (size_t)m * p.ldc + nf;
@@ -479,6 +507,8 @@ __device__ __forceinline__ void wave_epilogue(const GemmParams& p, const f32x4 (
         const f32x4 lo = *reinterpret_cast<const f32x4*>(Wt + rl * 64 + (((2 * c8) ^ (rl & 15)) << 2));
         const f32x4 hi = *reinterpret_cast<const f32x4*>(Wt + rl * 64 + (((2 * c8 + 1) ^ (rl & 15)) << 2));
         float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#pragma unroll
+        for (int r = 0; r < 8; ++r) { v[r] = rowbias ? v[r] + bia[r] : v[r]; v[r] = relu ? fmaxf(v[r], 0.f) : v[r]; }
         const int m = mb + rl;
         if (m >= p.M || !ncol) continue;
         if (relu_mask) {
@@ -1333,7 +1363,7 @@ __device__ __forceinline__ void gemm_bf16_256_body(const GemmParams& p, const in
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) part[i][j] = acc[4 * h + i][j];
-        wave_epilogue<ALAY, BLAY, 4>(p, part, m0 + wr * 128 + h * 64, n0 + wc * 64, z, Wt, lane, lsum);
+        wave_epilogue<ALAY, BLAY, 4, false, false>(p, part, m0 + wr * 128 + h * 64, n0 + wc * 64, z, Wt, lane, lsum);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the wave's own LDS reads of pass 0 are done before pass 1 overwrites Wt
     }
 #ifdef AFR_GEMM_TIMING
@@ -1715,6 +1745,8 @@ static bool bf16_use_wide(const GemmParams& p) {
     // a fused-AdamW epilogue moves 26 B per output element and is the longer half of such a kernel; two 128x128 blocks
     // per CU (64 KiB of LDS each) let one block's epilogue run under the other's K loop, one 256x128 block cannot
     if (p.ad_p) return false;
+    static const int narrow_k = getenv("AFR_GEMM_NARROW_K") ? atoi(getenv("AFR_GEMM_NARROW_K")) : 0;     // kernel A/B measurements
+    if (narrow_k && p.K / p.splitk <= narrow_k) return false;
     const long long t = (long long)((p.M + 255) / 256) * ((p.N + 127) / 128) * p.splitk;
     // a wide grid that leaves CUs idle loses to the 128x128 kernel at two blocks per CU (R0 dX: 200 wide tiles 323 us,
     // 400 narrow ones 302 us); from a full round on the two run level and wide needs fewer L2->LDS bytes

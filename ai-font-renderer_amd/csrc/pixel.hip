@@ -50,6 +50,19 @@ __device__ __forceinline__ void row_layernorm(float (&v)[8], const float* __rest
         for (int j = 0; j < 8; ++j) v[j] = fmaf(v[j] * rstd, g[c0 + j], b[c0 + j]);
     }
 }
+// the same with the affine parameters of the lane's 8 channels already in registers
+__device__ __forceinline__ void row_layernorm_r(float (&v)[8], const float (&g)[8], const float (&b)[8], int d, float eps, bool live) {
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += live ? v[j] : 0.f;
+    const float mu = wave_sum(s) / (float)d;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { v[j] -= mu; q = live ? fmaf(v[j], v[j], q) : q; }
+    const float rstd = rsqrtf(wave_sum(q) / (float)d + eps);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = fmaf(v[j] * rstd, g[j], b[j]);
+}
 }  // namespace
 
 // ctx[b][0] = Emb[x_b], ctx[b][1] = Font[f_b]  (model.py:136,167 gather; index check as the glyph kernels)
@@ -212,7 +225,12 @@ hipError_t afr_launch_pixel_head(int act_dtype, const float* hin, float* h, cons
 // as ONE slab per block ([nblk][...], block order), which the grouped reduce adds in fixed order: bitwise reproducible.
 namespace {
 constexpr int PIX_BWD_BLOCKS = 512;        // blocks of the backward token kernels = slabs per LayerNorm / head gradient
-// sum the 4 waves' per-lane partials (8 channels each, K arrays) through LDS and store wave 0's total: slab[k][d]
+constexpr int PIX_BWD_WAVES = 16;          // waves per block: 2 blocks x 16 waves fill a CU's wave slots (these kernels live on loads in flight:
+                                           // with 4-wave blocks pixel_ln_bwd ran at 3.8 TB/s and pixel_head_bwd at 1.6 TB/s)
+constexpr int PIX_BWD_THREADS = 64 * PIX_BWD_WAVES;
+// sum the waves' per-lane partials (8 channels each, K arrays) through LDS in wave order and store the total: slab[k][d]
+// (sh: (PIX_BWD_WAVES - 1) * 512 floats; lane-major rows of 8 floats + 1 pad keep the 64 lanes on distinct banks)
+constexpr int PIX_SH_FLOATS = (PIX_BWD_WAVES - 1) * 64 * 9;
 template <int K>
 __device__ __forceinline__ void block_store_partials(float (&acc)[K][8], float* slab, int d, int c0, bool live, float* sh) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -221,13 +239,16 @@ __device__ __forceinline__ void block_store_partials(float (&acc)[K][8], float* 
     for (int k = 0; k < K; ++k) {
         if (wave > 0) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) sh[((wave - 1) * 64 + lane) * 8 + j] = acc[k][j];
+            for (int j = 0; j < 8; ++j) sh[((wave - 1) * 64 + lane) * 9 + j] = acc[k][j];
         }
         __syncthreads();
         if (wave == 0 && live) {
             float out[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) out[j] = ((acc[k][j] + sh[(0 * 64 + lane) * 8 + j]) + sh[(1 * 64 + lane) * 8 + j]) + sh[(2 * 64 + lane) * 8 + j];
+            for (int j = 0; j < 8; ++j) out[j] = acc[k][j];
+            for (int w = 0; w < PIX_BWD_WAVES - 1; ++w)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) out[j] += sh[(w * 64 + lane) * 9 + j];
             *reinterpret_cast<float4*>(slab + (size_t)k * d + c0) = make_float4(out[0], out[1], out[2], out[3]);
             *reinterpret_cast<float4*>(slab + (size_t)k * d + c0 + 4) = make_float4(out[4], out[5], out[6], out[7]);
         }
@@ -235,7 +256,7 @@ __device__ __forceinline__ void block_store_partials(float (&acc)[K][8], float* 
     }
 }
 // LayerNorm backward of one row: x (pre-norm input), dy (gradient of the affine output) -> dx; accumulates dgamma, dbeta
-__device__ __forceinline__ void row_ln_bwd(const float (&x)[8], const float (&dy)[8], const float* __restrict__ g, int c0, int d, float eps, bool live,
+__device__ __forceinline__ void row_ln_bwd(const float (&x)[8], const float (&dy)[8], const float (&g)[8], int d, float eps, bool live,
                                            float (&dx)[8], float (&dg)[8], float (&db)[8]) {
     float s = 0.f;
 #pragma unroll
@@ -250,7 +271,7 @@ __device__ __forceinline__ void row_ln_bwd(const float (&x)[8], const float (&dy
     for (int j = 0; j < 8; ++j) {
         const float xh = xc[j] * rstd;
         xc[j] = xh;
-        gg[j] = live ? dy[j] * g[c0 + j] : 0.f;
+        gg[j] = live ? dy[j] * g[j] : 0.f;
         m1 += gg[j]; m2 = fmaf(gg[j], xh, m2);
         if (live) { dg[j] = fmaf(dy[j], xh, dg[j]); db[j] += dy[j]; }
     }
@@ -261,10 +282,10 @@ __device__ __forceinline__ void row_ln_bwd(const float (&x)[8], const float (&dy
 }  // namespace
 // head backward: du [rows] -> dh = LN_f-backward(du * w_out); partials [nblk][4][d]: dgamma_f, dbeta_f, dw_out, (db_out in [3][0])
 template <typename T>
-__global__ __launch_bounds__(256) void pixel_head_bwd_kernel(const float* __restrict__ du, const float* __restrict__ hf, const float* __restrict__ g,
+__global__ __launch_bounds__(PIX_BWD_THREADS) void pixel_head_bwd_kernel(const float* __restrict__ du, const float* __restrict__ hf, const float* __restrict__ g,
                                                              const float* __restrict__ bta, const float* __restrict__ w_out, float* __restrict__ dh,
                                                              T* __restrict__ dhT, float* __restrict__ part, long long rows, int d, float eps) {
-    __shared__ float sh[3 * 64 * 8];
+    __shared__ float sh[PIX_SH_FLOATS];
     const int lane = threadIdx.x & 63, c0 = 8 * lane;
     const bool live = c0 < d;
     float acc[4][8];
@@ -272,20 +293,29 @@ __global__ __launch_bounds__(256) void pixel_head_bwd_kernel(const float* __rest
     for (int k = 0; k < 4; ++k)
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[k][j] = 0.f;
-    for (long long r = blockIdx.x * 4ll + (threadIdx.x >> 6); r < rows; r += (long long)gridDim.x * 4) {
-        float x[8], dy[8], dx[8];
+    // per-lane constants (8 channels) once; the next row's loads are requested before this row's arithmetic (a wave walks
+    // only rows / (blocks * waves) rows: without the prefetch every row pays a full memory latency)
+    float gv[8], bv[8], wv[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) x[j] = 0.f;
-        if (live) ld8v(hf + (size_t)r * d + c0, x);
-        const float dur = du[r];
+    for (int j = 0; j < 8; ++j) { gv[j] = live ? g[c0 + j] : 0.f; bv[j] = live ? bta[c0 + j] : 0.f; wv[j] = live ? w_out[c0 + j] : 0.f; }
+    const long long stride = (long long)gridDim.x * PIX_BWD_WAVES;
+    long long r = (long long)blockIdx.x * PIX_BWD_WAVES + (threadIdx.x >> 6);
+    float x[8], xn[8], dur = 0.f, durn = 0.f;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) dy[j] = live ? dur * w_out[c0 + j] : 0.f;
+    for (int j = 0; j < 8; ++j) x[j] = xn[j] = 0.f;
+    if (r < rows) { if (live) ld8v(hf + (size_t)r * d + c0, x); dur = du[r]; }
+    for (; r < rows; r += stride) {
+        const long long rn = r + stride;
+        if (rn < rows) { if (live) ld8v(hf + (size_t)rn * d + c0, xn); durn = du[rn]; }
+        float dy[8], dx[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dy[j] = dur * wv[j];
         // nf = LN_f(hf) for dw_out: recomputed (xhat * g + b)
         float xs[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) xs[j] = x[j];
-        row_layernorm(xs, g, bta, c0, d, eps, live);
-        row_ln_bwd(x, dy, g, c0, d, eps, live, dx, acc[0], acc[1]);
+        row_layernorm_r(xs, gv, bv, d, eps, live);
+        row_ln_bwd(x, dy, gv, d, eps, live, dx, acc[0], acc[1]);
         if (live) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) acc[2][j] = fmaf(dur, xs[j], acc[2][j]);
@@ -295,15 +325,18 @@ __global__ __launch_bounds__(256) void pixel_head_bwd_kernel(const float* __rest
             *reinterpret_cast<float4*>(o + 4) = make_float4(dx[4], dx[5], dx[6], dx[7]);
             if (dhT) st8v(dhT + (size_t)r * d + c0, dx);
         }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] = xn[j];
+        dur = durn;
     }
     block_store_partials<4>(acc, part + (size_t)blockIdx.x * 4 * d, d, c0, live, sh);
 }
 // LayerNorm backward with the residual: dh <- dh + LN-backward(dy; x = hin);  partials [nblk][2][d]: dgamma, dbeta
 template <typename T>
-__global__ __launch_bounds__(256) void pixel_ln_bwd_kernel(const T* __restrict__ dyT, const float* __restrict__ hin, const float* __restrict__ g,
+__global__ __launch_bounds__(PIX_BWD_THREADS) void pixel_ln_bwd_kernel(const T* __restrict__ dyT, const float* __restrict__ hin, const float* __restrict__ g,
                                                            float* __restrict__ dh, T* __restrict__ dhT, float* __restrict__ part, long long rows, int d,
                                                            float eps) {
-    __shared__ float sh[3 * 64 * 8];
+    __shared__ float sh[PIX_SH_FLOATS];
     const int lane = threadIdx.x & 63, c0 = 8 * lane;
     const bool live = c0 < d;
     float acc[2][8];
@@ -311,28 +344,38 @@ __global__ __launch_bounds__(256) void pixel_ln_bwd_kernel(const T* __restrict__
     for (int k = 0; k < 2; ++k)
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[k][j] = 0.f;
-    for (long long r = blockIdx.x * 4ll + (threadIdx.x >> 6); r < rows; r += (long long)gridDim.x * 4) {
-        float x[8], dy[8], dx[8], res[8];
+    float gv[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) x[j] = dy[j] = res[j] = 0.f;
-        if (live) { ld8v(hin + (size_t)r * d + c0, x); ld8v(dyT + (size_t)r * d + c0, dy); ld8v(dh + (size_t)r * d + c0, res); }
-        row_ln_bwd(x, dy, g, c0, d, eps, live, dx, acc[0], acc[1]);
+    for (int j = 0; j < 8; ++j) gv[j] = live ? g[c0 + j] : 0.f;
+    const long long stride = (long long)gridDim.x * PIX_BWD_WAVES;
+    long long r = (long long)blockIdx.x * PIX_BWD_WAVES + (threadIdx.x >> 6);
+    float x[8], dy[8], res[8], xn[8], dyn[8], resn[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) x[j] = dy[j] = res[j] = xn[j] = dyn[j] = resn[j] = 0.f;
+    if (r < rows && live) { ld8v(hin + (size_t)r * d + c0, x); ld8v(dyT + (size_t)r * d + c0, dy); ld8v(dh + (size_t)r * d + c0, res); }
+    for (; r < rows; r += stride) {
+        const long long rn = r + stride;            // (a row is read and written by this wave only: the prefetch of row rn never races a store)
+        if (rn < rows && live) { ld8v(hin + (size_t)rn * d + c0, xn); ld8v(dyT + (size_t)rn * d + c0, dyn); ld8v(dh + (size_t)rn * d + c0, resn); }
+        float dx[8];
+        row_ln_bwd(x, dy, gv, d, eps, live, dx, acc[0], acc[1]);
         if (live) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) res[j] += dx[j];
             st8v(dh + (size_t)r * d + c0, res);
             if (dhT) st8v(dhT + (size_t)r * d + c0, res);
         }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { x[j] = xn[j]; dy[j] = dyn[j]; res[j] = resn[j]; }
     }
     block_store_partials<2>(acc, part + (size_t)blockIdx.x * 2 * d, d, c0, live, sh);
 }
 // cross-attention backward (C <= 2 keys): do, q, kv -> dq [rows][d]; dk | dv of the sample's context tokens summed over a
 // chunk of its tokens: dkv_part [chunks][B][2][2 d] -- one slab per chunk, so ONE slab reduce over the chunks finishes every
-// sample's sums (block = (sample, chunk); the 4 waves' sums are added in wave order)
+// sample's sums (block = (sample, chunk); the waves' sums are added in wave order)
 template <typename T>
-__global__ __launch_bounds__(256) void pixel_attn_bwd_kernel(const T* __restrict__ dO, const T* __restrict__ q, const T* __restrict__ kv, T* __restrict__ dq,
+__global__ __launch_bounds__(PIX_BWD_THREADS) void pixel_attn_bwd_kernel(const T* __restrict__ dO, const T* __restrict__ q, const T* __restrict__ kv, T* __restrict__ dq,
                                                              float* __restrict__ dkv_part, int Tk, int chunk, int d, int C) {
-    __shared__ float sh[3 * 64 * 8];
+    __shared__ float sh[PIX_SH_FLOATS];
     const int lane = threadIdx.x & 63, c0 = 8 * lane, wave = threadIdx.x >> 6;
     const bool live = c0 < d;
     const int chunks = (Tk + chunk - 1) / chunk;
@@ -349,7 +392,7 @@ __global__ __launch_bounds__(256) void pixel_attn_bwd_kernel(const T* __restrict
     for (int c = 0; c < C; ++c)
         if (live) { const T* kr = kv + ((size_t)b * C + c) * 2 * d; ld8v(kr + c0, kk[c]); ld8v(kr + d + c0, vv[c]); }
     const int t1 = min(Tk, (ch + 1) * chunk);
-    for (int t = ch * chunk + wave; t < t1; t += 4) {
+    for (int t = ch * chunk + wave; t < t1; t += PIX_BWD_WAVES) {
         const size_t r = (size_t)b * Tk + t;
         float qv[8], dov[8], s[2] = {0.f, 0.f}, dp[2] = {0.f, 0.f};
 #pragma unroll
@@ -415,27 +458,27 @@ __global__ __launch_bounds__(256) void pixel_cast_kernel(T* __restrict__ dst, co
         dst[i] = pcvt<T>(src[r * ld_src + (i - r * w)]);
     }
 }
-int afr_pixel_bwd_blocks(long long rows) { long long g = (rows + 3) / 4; return (int)(g < 1 ? 1 : (g > PIX_BWD_BLOCKS ? PIX_BWD_BLOCKS : g)); }
+int afr_pixel_bwd_blocks(long long rows) { long long g = (rows + PIX_BWD_WAVES - 1) / PIX_BWD_WAVES; return (int)(g < 1 ? 1 : (g > PIX_BWD_BLOCKS ? PIX_BWD_BLOCKS : g)); }
 hipError_t afr_launch_pixel_head_bwd(int act_dtype, const float* du, const float* hf, const float* g, const float* b, const float* w_out, float* dh,
                                      void* dhT, float* part, long long rows, int d, float eps, hipStream_t s) {
     const int grid = afr_pixel_bwd_blocks(rows);
-    if (act_dtype == AFR_BF16) hipLaunchKernelGGL(pixel_head_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, du, hf, g, b, w_out, dh, (bf16_t*)dhT, part, rows, d, eps);
-    else hipLaunchKernelGGL(pixel_head_bwd_kernel<float>, dim3(grid), dim3(256), 0, s, du, hf, g, b, w_out, dh, (float*)nullptr, part, rows, d, eps);
+    if (act_dtype == AFR_BF16) hipLaunchKernelGGL(pixel_head_bwd_kernel<bf16_t>, dim3(grid), dim3(PIX_BWD_THREADS), 0, s, du, hf, g, b, w_out, dh, (bf16_t*)dhT, part, rows, d, eps);
+    else hipLaunchKernelGGL(pixel_head_bwd_kernel<float>, dim3(grid), dim3(PIX_BWD_THREADS), 0, s, du, hf, g, b, w_out, dh, (float*)nullptr, part, rows, d, eps);
     return hipGetLastError();
 }
 hipError_t afr_launch_pixel_ln_bwd(int act_dtype, const void* dy, const float* hin, const float* g, float* dh, void* dhT, float* part, long long rows,
                                    int d, float eps, hipStream_t s) {
     const int grid = afr_pixel_bwd_blocks(rows);
-    if (act_dtype == AFR_BF16) hipLaunchKernelGGL(pixel_ln_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)dy, hin, g, dh, (bf16_t*)dhT, part, rows, d, eps);
-    else hipLaunchKernelGGL(pixel_ln_bwd_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)dy, hin, g, dh, (float*)nullptr, part, rows, d, eps);
+    if (act_dtype == AFR_BF16) hipLaunchKernelGGL(pixel_ln_bwd_kernel<bf16_t>, dim3(grid), dim3(PIX_BWD_THREADS), 0, s, (const bf16_t*)dy, hin, g, dh, (bf16_t*)dhT, part, rows, d, eps);
+    else hipLaunchKernelGGL(pixel_ln_bwd_kernel<float>, dim3(grid), dim3(PIX_BWD_THREADS), 0, s, (const float*)dy, hin, g, dh, (float*)nullptr, part, rows, d, eps);
     return hipGetLastError();
 }
 int afr_pixel_attn_chunk(int Tk) { return Tk <= 256 ? Tk : 256; }
 hipError_t afr_launch_pixel_attn_bwd(int act_dtype, const void* dO, const void* q, const void* kv, void* dq, float* dkv_part, int B, int Tk, int d, int C,
                                      hipStream_t s) {
     const int chunk = afr_pixel_attn_chunk(Tk), chunks = (Tk + chunk - 1) / chunk;
-    if (act_dtype == AFR_BF16) hipLaunchKernelGGL(pixel_attn_bwd_kernel<bf16_t>, dim3(B * chunks), dim3(256), 0, s, (const bf16_t*)dO, (const bf16_t*)q, (const bf16_t*)kv, (bf16_t*)dq, dkv_part, Tk, chunk, d, C);
-    else hipLaunchKernelGGL(pixel_attn_bwd_kernel<float>, dim3(B * chunks), dim3(256), 0, s, (const float*)dO, (const float*)q, (const float*)kv, (float*)dq, dkv_part, Tk, chunk, d, C);
+    if (act_dtype == AFR_BF16) hipLaunchKernelGGL(pixel_attn_bwd_kernel<bf16_t>, dim3(B * chunks), dim3(PIX_BWD_THREADS), 0, s, (const bf16_t*)dO, (const bf16_t*)q, (const bf16_t*)kv, (bf16_t*)dq, dkv_part, Tk, chunk, d, C);
+    else hipLaunchKernelGGL(pixel_attn_bwd_kernel<float>, dim3(B * chunks), dim3(PIX_BWD_THREADS), 0, s, (const float*)dO, (const float*)q, (const float*)kv, (float*)dq, dkv_part, Tk, chunk, d, C);
     return hipGetLastError();
 }
 hipError_t afr_launch_pixel_ctx_bwd(const float* dctx, const int64_t* x, const int64_t* font, int B, int d, int vocab, int n_fonts, float* demb, float* dfont,
