@@ -70,6 +70,31 @@ def test_gemm_epilogues_and_splitk(dtype):
         assert float((got.double() - ref).abs().max()) < 1e-4 * scale, sk
 
 
+def test_bf16_gemm_with_a_thousand_256x256_tiles_takes_the_256x256_body_and_matches_fp64():
+    """Plain bf16 products whose 256x256 tiles make four or more rounds of the chip run on the 256x256 body (gemm.hip
+    bf16_use_body256; the pixel transformer's 131072-row products): every layout the training path uses there, ragged in M,
+    with the bias / ReLU / bf16-output / ReLU-gate epilogues, against fp64."""
+    from .gpu_util import gemm
+    M, N, K = 65536 + 40, 1024, 256                     # 257 x 4 tiles
+    A, B = _b16(_rand(61, (M, K))), _b16(_rand(62, (N, K), 0.2))
+    bias, aux = _rand(63, (N,)), _b16(_rand(64, (M, N)))
+    ref = A.double() @ B.double().t()
+    scale = float(ref.abs().max())
+    got = gemm("bf16", A, B)
+    assert float((got.double() - ref).abs().max()) < 1e-5 * scale
+    got = gemm("bf16", A, B, bias=bias, relu=True, out_bf16=True)
+    assert float((got.double() - torch.relu(ref + bias.double())).abs().max()) < 1e-2 * scale
+    got = gemm("bf16", A, B, b_kstrided=True, aux=aux, out_bf16=True)
+    assert float((got.double() - ref * (aux > 0)).abs().max()) < 1e-2 * scale
+    del ref, got, aux
+    # the forward layout with a long K and few columns (fc2: 2048 -> 512)
+    M, N, K = 131072, 512, 512
+    A, B = _b16(_rand(65, (M, K))), _b16(_rand(66, (N, K), 0.2))
+    ref = A.double() @ B.double().t()
+    got = gemm("bf16", A, B, bias=_rand(67, (N,)), out_bf16=True)
+    assert float((got.double() - (ref + _rand(67, (N,)).double())).abs().max()) < 1e-2 * float(ref.abs().max())
+
+
 def test_f32_gemm_is_a_k_ordered_fma_chain_close_to_fp64():
     """Parity mode: exact-f32 MFMA, error ~1e-7 * sum|a b| (the 1e-4 bitmap bar needs K=6400 products)."""
     from .gpu_util import gemm
