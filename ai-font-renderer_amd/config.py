@@ -157,6 +157,9 @@ WORKLOADS = {
     "c2": dict(cfg=GlyphConfig(hidden=(256,), out_h=16, out_w=16), batch=4096),
     "c3": dict(cfg=GlyphConfig(hidden=(1024, 1024), out_h=32, out_w=32, n_fonts=2), batch=8192),
 }
-# BASELINE configs[4] and the miniature the parity fixtures pin (tests/golden/pixel_twin.npz); no engine path yet: DESIGN.md 8
+# BASELINE configs[4] and the miniature the parity fixtures pin (tests/golden/pixel_twin.npz): DESIGN.md 8
 C5 = PixelConfig()
 C5_MINI = PixelConfig(out_h=8, out_w=8)
+# one micro-batch of configs[4] per step: 32 glyphs = 131072 pixel tokens, 12.6 GB of saved activations in bf16 mode (the configured
+# 2048 glyphs per GPU are 64 such micro-batches; every product already has M = 131072 rows)
+WORKLOADS["c5"] = dict(cfg=C5, batch=32)

@@ -634,7 +634,12 @@ static int run_gemm(afr_plan* p, hipStream_t s, int flags, const void* A, const 
         HIPCHK(afr_launch_gemm_fix(g, s));
         return AFR_OK;
     }
-    snprintf(tag, sizeof tag, "%s[%dx%dx%d]", afr_gemm_kernel_name(p->cfg.dtype, g), M, N, K);
+    {
+        const char* kn = afr_gemm_kernel_name(p->cfg.dtype, g);
+        if (strcmp(kn, "gemm_bf16_group256") == 0)     // a plain product on the 256x256 body: the operand orientation follows the shape
+            snprintf(tag, sizeof tag, "%s[%dx%dx%d]<%d,%d>", kn, M, N, K, (flags & AFR_GEMM_A_KSTRIDED) ? 1 : 0, (flags & AFR_GEMM_B_KSTRIDED) ? 1 : 0);
+        else snprintf(tag, sizeof tag, "%s[%dx%dx%d]", kn, M, N, K);
+    }
     if (coop && !(p->defer && p->pend_tile256 && p->pend.empty() && afr_gemm_groupable(p->cfg.dtype, g)))
         return fail(AFR_ESTATE, "cooperative split-K product outside a 256x256 grouped launch");
     if (rm && rm->b && !(p->defer && p->pend_tile256 && afr_gemm_groupable(p->cfg.dtype, g)))

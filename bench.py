@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- glyphs/sec of one full training step (forward + MSE + backward + AdamW) of the hot path.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3|c2|c1|r0] [--dtype bf16|f32]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3|c2|c1|r0|c5] [--dtype bf16|f32]
          (run directly with N > 1 it starts its own N rank processes before touching a GPU)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
          bench.py --gpus N --steps K --warmup W          (one rank per GPU, RCCL)
@@ -13,6 +13,8 @@ Workloads (BASELINE.json configs) -- per-GPU batch is fixed, so sc
   c2            16x16 glyphs, hidden 256, bf16, 4096 glyphs (configs[1]; launch-latency bound)
   c1            same net, fp32, 95 glyphs (configs[0], the CPU-runnable case)
   r0            the reference's own AttentionFontRenderer (80x240 sheets of <=100 chars), 1024 sheets per GPU
+  c5            configs[4]'s per-pixel-token transformer as DESIGN.md 8 defines it (64x64 tokens, d_model 512, 4 blocks), bf16
+                operands, ONE micro-batch of 32 glyphs (131072 token rows) per step -- not the fp8 / 2048-per-GPU form of the config
 Before the W warm-up steps the GPU is pre-heated with inference forwards of the same model (--preheat-ms, default 30 ms of
 host time; reported as "preheat_ms"): the part needs ~20 ms of sustained work to reach its operating point.
 Inputs are synthetic and resident in HBM before the timed region: the 95 printable ASCII codes (x font ids) repeated over
@@ -32,7 +34,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 from ai_font_renderer_amd import synth  # noqa: E402
-from ai_font_renderer_amd.config import WORKLOADS, SheetConfig  # noqa: E402
+from ai_font_renderer_amd.config import WORKLOADS, PixelConfig, SheetConfig  # noqa: E402
 
 PEAK = {"bf16": 2500.0, "f32": 157.3}        # dense MFMA TFLOP/s, MI355X_MICROARCH.md chip table
 HBM_PEAK_GBS = 8000.0
@@ -41,9 +43,10 @@ DESCR = {
     "c2": "C2: 16x16 glyph MLP 32->256->256, batch 4096 (BASELINE configs[1])",
     "c1": "C1: 16x16 glyph MLP 32->256->256, fp32, batch 95 (BASELINE configs[0])",
     "r0": "R0: reference AttentionFontRenderer, 100 chars -> 80x240 sheet, batch 1024/GPU",
+    "c5": "C5 micro-batch: 64x64 per-pixel-token transformer (d_model 512, 8 heads, 4 blocks, ff 2048; DESIGN.md 8), bf16 operands, 32 glyphs = 131072 tokens/GPU (BASELINE configs[4] asks fp8 and 2048 glyphs/GPU)",
 }
-DEFAULT_DTYPE = {"c3": "bf16", "c2": "bf16", "c1": "f32", "r0": "bf16"}
-DEFAULT_STEPS = {"c3": (200, 20), "c2": (500, 50), "c1": (500, 50), "r0": (30, 5)}
+DEFAULT_DTYPE = {"c3": "bf16", "c2": "bf16", "c1": "f32", "r0": "bf16", "c5": "bf16"}
+DEFAULT_STEPS = {"c3": (200, 20), "c2": (500, 50), "c1": (500, 50), "r0": (30, 5), "c5": (20, 3)}
 
 
 def make_inputs(name, cfg, B, rank):
@@ -57,6 +60,9 @@ def make_inputs(name, cfg, B, rank):
     x = (32 + (i % 95)).astype(np.int64)                              # the 95 printable ASCII codes, repeated
     font = ((i // 95) % max(cfg.n_fonts, 1)).astype(np.int64)
     t = synth.glyph_bitmap_targets(cfg.out_h, x, font) if cfg.out_h == cfg.out_w else None     # FiraCode (+ Montserrat) glyphs
+    if t is None and cfg.out_h == cfg.out_w == 64:
+        t32 = synth.glyph_bitmap_targets(32, x, font)                 # 64x64: the 32x32 rasterisations, every pixel doubled
+        t = np.repeat(np.repeat(t32, 2, axis=1), 2, axis=2) if t32 is not None else None
     if t is None:
         t = synth.hash_u8(950 + rank, (B, cfg.out_h, cfg.out_w))
     return torch.from_numpy(x), (torch.from_numpy(font) if cfg.n_fonts > 0 else None), torch.from_numpy(t)
@@ -81,6 +87,8 @@ def reference_bitmap_diff(cfg, sample):
     P = sample["params"]
     if isinstance(cfg, SheetConfig):
         yref, _ = oracle.sheet_forward(P, sample["x"], cfg)
+    elif isinstance(cfg, PixelConfig):
+        yref, _ = oracle.pixel_forward(P, sample["x"], sample["font"], cfg)
     else:
         yref, _ = oracle.glyph_forward(P, sample["x"], sample["font"], cfg)
     return float((sample["y"].reshape(yref.shape) - yref).abs().max())
@@ -91,6 +99,8 @@ def cpu_baseline(name, cfg, B, budget_s=12.0):
     from oracle import afr_oracle as oracle            # checker / baseline only -- never on the product path
     cores = host_cores()
     torch.set_num_threads(cores)
+    if isinstance(cfg, PixelConfig):
+        B = min(B, 2)                                  # 258 GFLOP per glyph and step: a bounded sample of the same step
     x, font, t = make_inputs(name, cfg, B, 0)
     tgt = t.to(torch.float32) / 255.0
     P = {k: torch.from_numpy(v) for k, v in synth.make_params(cfg).items()}
@@ -152,6 +162,8 @@ def step_flops(cfg, B):
         L, E, F, H = cfg.max_length, cfg.embed_dim, cfg.fc_dim, cfg.heads
         fwd = 2.0 * L * (E * 3 * E + E * E + E * F) + 2.0 * 2 * L * L * E + 2.0 * (L * F) * cfg.pixels      # 248.27 MFLOP at R0
         return 3.0 * fwd * B
+    if isinstance(cfg, PixelConfig):
+        return cfg.train_flops_per_sample() * B
     return 3.0 * B * sum(2.0 * n * k for n, k in cfg.layer_dims())
 
 
@@ -159,6 +171,8 @@ def widest_linear(cfg):
     """(N, K) of the widest Linear: fc_output for the sheet model, the hidden x hidden layers of the glyph nets."""
     if isinstance(cfg, SheetConfig):
         return cfg.pixels, cfg.max_length * cfg.fc_dim
+    if isinstance(cfg, PixelConfig):
+        return cfg.ff_dim, cfg.d_model
     return max(cfg.layer_dims(), key=lambda nk: nk[0] * nk[1])
 
 
@@ -242,7 +256,12 @@ def measure(name, dtype, B, K, W, rank, world, dist, with_roofline=True, want_sa
         raise SystemExit("device error flag set (embedding index out of range / cooperative split-K timeout)")
     # a sample of the bitmaps the trained engine draws, with its f32 master weights, for the max-abs-diff leg (rank 0, CPU side)
     if rank == 0 and want_sample:
-        ns = min(B, 16 if isinstance(cfg, SheetConfig) else 190)
+        ns = min(B, 16 if isinstance(cfg, SheetConfig) else 2 if isinstance(cfg, PixelConfig) else 190)
+        if isinstance(cfg, PixelConfig):
+            # after the run's steps at the default learning rate the transformer draws saturated (all-zero) bitmaps, on which every
+            # precision agrees: its bitmaps are compared on the initial weights instead
+            eng.load_params(synth.make_params(cfg))
+            x, font = torch.tensor([40, 77]).cuda(), torch.tensor([0, 1]).cuda()     # ('(', font 0), ('M', font 1): half their pixels land inside (0, 1)
         xs, fs = x[:ns], (font[:ns] if font is not None else None)
         eng.sample = {"x": xs.cpu(), "font": fs.cpu() if fs is not None else None, "y": eng.forward(xs, fs).cpu(),
                       "params": {k: v.cpu() for k, v in eng.state_dict().items()}}
@@ -333,12 +352,15 @@ def main():
         roof["step"] = {"algo_flops": sf, "achieved_tflops": sf / (ms_step * 1e-3) / 1e12, "peak": PEAK[dtype],
                         "frac": sf / (ms_step * 1e-3) / 1e12 / PEAK[dtype]}
         wn, wk = widest_linear(cfg)
+        Bm = B * cfg.tokens if isinstance(cfg, PixelConfig) else B          # rows of a Linear's products (every pixel token is a row)
         # (operand orientation, MxNxK) of the three products: forward x.W^T, input gradient dy.W, weight gradient dy^T.x
-        shapes = {"fwd": ("<0,0", f"[{B}x{wn}x{wk}]"), "dX": ("<0,1", f"[{B}x{wk}x{wn}]"), "dW": ("<1,1", f"[{wn}x{wk}x{B}]")}
+        shapes = {"fwd": ("<0,0", f"[{Bm}x{wn}x{wk}]"), "dX": ("<0,1", f"[{Bm}x{wk}x{wn}]"), "dW": ("<1,1", f"[{wn}x{wk}x{Bm}]")}
         wl = {}
         for r in table:
             for role, (ori, sh) in shapes.items():
-                if r["kernel"].startswith("gemm") and ori in r["kernel"] and r["kernel"].endswith(sh) and role not in wl and r["avg_ms"] > 0:
+                plain = r["kernel"].startswith("gemm") and ori in r["kernel"] and r["kernel"].endswith(sh)
+                body = r["kernel"].startswith("gemm_bf16_group256" + sh + ori)          # a plain product on the 256x256 body: name[shape]<a,b>
+                if (plain or body) and role not in wl and r["avg_ms"] > 0:
                     tf = r["algo_flops"] / (r["avg_ms"] * 1e-3) / 1e12
                     wl[role] = {"kernel": r["kernel"], "avg_us": r["avg_ms"] * 1e3, "tflops": tf, "frac": tf / (PEAK["f32"] if "f32" in r["kernel"] else PEAK[dtype])}
         # a layer's weight and input gradients leave as ONE grouped launch when both qualify (afr_gemm_pair_plan)
@@ -390,6 +412,9 @@ def main():
             # max-abs bitmap diff vs the CPU reference path, for the benchmarked dtype and for the parity mode
             note = ("engine eval forward after the run's training steps vs the f32 oracle on the engine's own f32 master weights; "
                     "%d samples; tests assert <= 2.5e-2 (bf16) / 2e-5 (f32): tests/test_gpu_models.py")
+            if isinstance(cfg, PixelConfig):
+                note = ("engine eval forward on the INITIAL weights (the trained net saturates) vs the f32 oracle; %d samples; "
+                        "tests assert <= 2.5e-2 (bf16) / 2e-5 (f32) at C5-mini size: tests/test_gpu_pixel.py")
             if samples.get(dtype):
                 out["max_abs_bitmap_diff"] = {"value": reference_bitmap_diff(cfg, samples[dtype]), "dtype": dtype,
                                               "note": note % samples[dtype]["y"].shape[0]}

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Collect the per-round profile evidence on the GPU box (run through gpurun from the repo root):
 #   tools/collect_profiles.sh <round, e.g. r03>
-# 1. bench logs (c1, c2, c3, r0)                         -> gpurun_out/<round>/bench_*.log
+# 1. bench logs (c1, c2, c3, r0, c5)                        -> gpurun_out/<round>/bench_*.log
 # 2. rocprofv3 --kernel-trace --stats of bench.py        -> gpurun_out/<round>/stats_{c3,r0}/
 # 3. PMC passes, each in its own run with no trace flags -> gpurun_out/<round>/pmc_{c3,r0}_{FETCH_SIZE,WRITE_SIZE,MFMA}/
 # The program follows `--` directly (python3 bench.py ...): no env / shell wrapper between rocprofv3 and it.
@@ -17,6 +17,10 @@ for w in c1 c2 c3 r0; do
 done
 python3 bench.py --steps 200 --warmup 20 > $O/bench_default.log 2>&1
 echo "bench default done"
+python3 bench.py --workload c5 --table > $O/bench_c5.log 2>&1          # one micro-batch of BASELINE configs[4]
+echo "bench c5 done"
+python3 tools/c5_step_bench.py 32 bf16 > $O/c5_step.log 2>&1
+echo "c5 step table done"
 for w in c1 c2; do       # the latency-bound small nets: kernel statistics only
   rocprofv3 --kernel-trace --stats -d $O/stats_$w -o $w -- python3 bench.py --workload $w $B > $O/stats_$w.log 2>&1
   echo "stats $w done"
