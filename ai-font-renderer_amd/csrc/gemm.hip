@@ -353,9 +353,28 @@ __device__ unsigned long long* g_gemm_stamps = nullptr;
 #endif
 // The epilogue of one wave's 64x64 f32 accumulator tile whose top-left element is (mb, nb0) of the product; Wt = the
 // wave's own 16 KiB of LDS.  Shared by the 256x128 / 128x128 kernels (one call) and the 256x256 kernel (two calls).
-template <int ALAY, int BLAY, int WM, bool SCALE = false, bool EARLYB_ = true>      // SCALE: the accumulators are multiplied by p.out_scale first (fp8 per-tensor scales)
-__device__ __forceinline__ void wave_epilogue(const GemmParams& p, const f32x4 (&acc)[4][4], const int mb, const int nb0, const int z,
-                                              float* Wt, const int lane, float& lsum, const float* lut255 = nullptr) {
+// the bias values a lane adds in the row-contiguous pass of wave_epilogue: its 8 (bf16 output) or 4 (f32 output) columns
+__device__ __forceinline__ void epilogue_bias(const GemmParams& p, const int nb0, const int lane, float (&bia)[8]) {
+#pragma unroll
+    for (int r = 0; r < 8; ++r) bia[r] = 0.f;
+    if (!(p.flags & AFR_GEMM_BIAS)) return;
+    if (p.flags & AFR_GEMM_OUT_BF16) {
+        const int n = nb0 + 8 * (lane & 7);
+        if (n < p.N) {
+            const float4 b0 = *reinterpret_cast<const float4*>(p.bias + n), b1 = *reinterpret_cast<const float4*>(p.bias + n + 4);
+            bia[0] = b0.x; bia[1] = b0.y; bia[2] = b0.z; bia[3] = b0.w; bia[4] = b1.x; bia[5] = b1.y; bia[6] = b1.z; bia[7] = b1.w;
+        }
+    } else if (nb0 + 4 * (lane & 15) < p.N) {
+        const float4 b0 = *reinterpret_cast<const float4*>(p.bias + nb0 + 4 * (lane & 15));
+        bia[0] = b0.x; bia[1] = b0.y; bia[2] = b0.z; bia[3] = b0.w;
+    }
+}
+// (acc_at(i, j): the wave's accumulator fragment of rows 16 i .., columns 16 j .. -- an accessor, so that the 256x256 body can hand
+// over either half of its 128 x 64 tile without copying 64 registers)
+template <int ALAY, int BLAY, int WM, bool SCALE = false, bool EARLYB_ = true, class ACC>      // SCALE: the accumulators are multiplied by p.out_scale first (fp8 per-tensor scales)
+__device__ __forceinline__ void wave_epilogue_at(const GemmParams& p, const ACC& acc_at, const int mb, const int nb0, const int z,
+                                                 float* Wt, const int lane, float& lsum, const float* lut255 = nullptr,
+                                                 const float (*pre_bias)[8] = nullptr) {
     // Epilogue through LDS: the MFMA accumulators hold 4 consecutive n of 16 different rows per lane-group, which as
     // direct stores would be 32-byte pieces.  Each wave parks its 64x64 f32 tile in its own 16 KiB of LDS (16-B chunks
     // XOR-swizzled by row: conflict-free both ways) and streams it out row-contiguous: 8 lanes x 8 values = one 64-col
@@ -373,22 +392,13 @@ __device__ __forceinline__ void wave_epilogue(const GemmParams& p, const f32x4 (
     // 4 (f32 output) columns of every row: its few bias values are requested HERE, before the accumulators are parked, so the
     // load's latency (2 us per tile on the K = 512 products of the pixel transformer when it was taken per accumulator
     // fragment at this point) passes under the LDS round trip.  Same f32 additions, same results.
-    // (EARLYB = false: the 256x256 body, which sits at the register limit with its other accumulator half still live here, adds
-    // the bias per accumulator fragment while parking, as every kernel did before)
-    float bia[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    auto load_bias = [&]() {
-        if (!(flags & AFR_GEMM_BIAS)) return;
-        if (out_bf16) {
-            if (ncol) {
-                const float4 b0 = *reinterpret_cast<const float4*>(p.bias + n), b1 = *reinterpret_cast<const float4*>(p.bias + n + 4);
-                bia[0] = b0.x; bia[1] = b0.y; bia[2] = b0.z; bia[3] = b0.w; bia[4] = b1.x; bia[5] = b1.y; bia[6] = b1.z; bia[7] = b1.w;
-            }
-        } else if (nb0 + 4 * (lane & 15) < p.N) {
-            const float4 b0 = *reinterpret_cast<const float4*>(p.bias + nb0 + 4 * (lane & 15));
-            bia[0] = b0.x; bia[1] = b0.y; bia[2] = b0.z; bia[3] = b0.w;
-        }
-    };
-    if (EARLYB) load_bias();
+    // (pre_bias: the 256x256 body calls twice for the same columns and asks once, before its first call.  EARLYB_ = false keeps
+    // the per-fragment form of every layout.)
+    float bia[8];
+    if (pre_bias) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) bia[r] = (*pre_bias)[r];
+    } else if (EARLYB) epilogue_bias(p, nb0, lane, bia);
     const bool relu = EARLYB && (flags & AFR_GEMM_RELU);
     const bool rowbias = EARLYB && (flags & AFR_GEMM_BIAS);
 #pragma unroll
@@ -397,7 +407,7 @@ __device__ __forceinline__ void wave_epilogue(const GemmParams& p, const f32x4 (
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int nl = 16 * j + 4 * (lane >> 4);
-            f32x4 v = acc[i][j];
+            f32x4 v = acc_at(i, j);
             if (SCALE) v *= p.out_scale;
             if (!EARLYB) {
                 if ((flags & AFR_GEMM_BIAS) && nb0 + nl < p.N) {
@@ -561,6 +571,12 @@ __device__ __forceinline__ void wave_epilogue(const GemmParams& p, const f32x4 (
             }
         }
     }
+}
+
+template <int ALAY, int BLAY, int WM, bool SCALE = false, bool EARLYB_ = true>
+__device__ __forceinline__ void wave_epilogue(const GemmParams& p, const f32x4 (&acc)[4][4], const int mb, const int nb0, const int z,
+                                              float* Wt, const int lane, float& lsum, const float* lut255 = nullptr) {
+    wave_epilogue_at<ALAY, BLAY, WM, SCALE, EARLYB_>(p, [&](int i, int j) { return acc[i][j]; }, mb, nb0, z, Wt, lane, lsum, lut255);
 }
 
 // Finish of one wave's 16 x 64 f32 strip of a weight gradient (cooperative split-K, gemm_bf16_256_body): v[j] holds rows
@@ -1356,14 +1372,17 @@ __device__ __forceinline__ void gemm_bf16_256_body(const GemmParams& p, const in
     // two passes of the 64x64 wave epilogue: accumulator rows 0..3 (tile rows wr*128 .. +63), then 4..7
     float lsum = 0.f;
     float* Wt = reinterpret_cast<float*>(smem) + wave * 4096;
+    // (a real loop over the halves -- two inlined copies of the epilogue break the DMA asm's scalar operands -- with the half
+    // picked by selects, never by a dynamic register index, which would be scratch)
+    float bia[8];
+    if (ALAY == 0 && BLAY == 0) epilogue_bias(p, n0 + wc * 64, lane, bia);       // one request for both halves, ahead of the first park
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-        f32x4 part[4][4];
+        wave_epilogue_at<ALAY, BLAY, 4, false, true>(p, [&](int i, int j) {
+            f32x4 v;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) part[i][j] = acc[4 * h + i][j];
-        wave_epilogue<ALAY, BLAY, 4, false, false>(p, part, m0 + wr * 128 + h * 64, n0 + wc * 64, z, Wt, lane, lsum);
+            for (int r = 0; r < 4; ++r) v[r] = h ? acc[4 + i][j][r] : acc[i][j][r];
+            return v; }, m0 + wr * 128 + h * 64, n0 + wc * 64, z, Wt, lane, lsum, nullptr, (ALAY == 0 && BLAY == 0) ? &bia : nullptr);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the wave's own LDS reads of pass 0 are done before pass 1 overwrites Wt
     }
 #ifdef AFR_GEMM_TIMING
