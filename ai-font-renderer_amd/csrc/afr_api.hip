@@ -951,13 +951,17 @@ extern "C" int afr_set_output_grad(afr_plan* p, const float* dy, int B, void* st
 // Backward runs in STAGES, last layer first; each stage finishes a contiguous range of the flat gradient buffer
 // (its own slab reduction included), so a data-parallel caller can start the all-reduce of that range while the
 // next stage computes.  Glyph: one stage per Linear (the first layer's stage also does the embedding tables).
-// Sheet: stage 0 = fc_output (dW + db), stage 1 = dz GEMM + fused front-end backward.  Pixel transformer: one stage.
+// Sheet: stage 0 = fc_output (dW + db), stage 1 = dz GEMM + fused front-end backward.  Pixel transformer: one stage per block.
 
 // Backward of the pixel-token transformer (reverse of forward_impl's AFR_KIND_PIXEL branch; oracle.pixel_backward): du (f32,
 // left in the u buffer by the loss) -> every parameter gradient.  Linears: the dW (+ fused db) and dX GEMMs of gemm.hip;
 // token-wise reverses: pixel.hip.  Slab-produced gradients (split-K dW, bias partials, LayerNorm / head partials) are registered
 // for a grouped reduce per block; the rest is written directly.
-static int pixel_backward(afr_plan* p, hipStream_t s) {
+// One STAGE per block, last block first (stage 0 also runs the head's reverse, the last stage the positional table and the
+// embedding rows): each finishes the contiguous range of the flat gradient buffer that holds its block's tensors (stage 0: from
+// the last block to the end; the last stage: from the start to the second block), so a data-parallel caller can reduce it while the
+// next stage computes.
+static int pixel_backward(afr_plan* p, hipStream_t s, int stage, int64_t* g_off, int64_t* g_len) {
     const afr_config& c = p->cfg;
     RTable rt;
     rt.nseg = 0; rt.nblocks = 0; rt.adam = 0;
@@ -970,7 +974,8 @@ static int pixel_backward(afr_plan* p, hipStream_t s) {
     void* dhT = c.dtype == AFR_BF16 ? (void*)(p->ws + p->o_dht) : (void*)dh;      // the GEMM-operand copy of dh (f32 mode: dh itself)
     void *dfb = p->ws + p->o_df, *dn = p->ws + p->o_dn, *dq = p->ws + p->o_dq, *ctx = p->ws + p->o_ctx;
     int rc;
-    {
+    const int nl = c.n_hidden, l = nl - 1 - stage;
+    if (stage == 0) {
         float* hp = (float*)(p->ws + p->o_headp);
         ProfScope ps(p, s, "pixel_head_bwd", 0.0, (double)rows * d * 12.0);
         HIPCHK(afr_launch_pixel_head_bwd(c.dtype, du, (const float*)(p->ws + p->o_hf), p->P + p->px_lnfg, p->P + p->px_lnfb, p->P + p->px_wout, dh,
@@ -980,7 +985,7 @@ static int pixel_backward(afr_plan* p, hipStream_t s) {
         afr_rtable_add(rt, p->G + p->px_wout, hp + 2 * d, nbp, 4ll * d, d);
         afr_rtable_add(rt, p->G + p->px_bout, hp + 3 * d, nbp, 4ll * d, 4);       // (element 0 is db_out; the 3 after it are zero: a 64-aligned tensor)
     }
-    for (int l = c.n_hidden - 1; l >= 0; --l) {
+    {
         const afr_plan::PixBlock& b = p->pix[l];
         const afr_plan::PixSave& sv = p->pxs[l];
         afr_plan::Layer* L5 = &p->pxl[(size_t)l * 5];                 // q, kv, out-proj, fc1, fc2
@@ -1033,6 +1038,10 @@ static int pixel_backward(afr_plan* p, hipStream_t s) {
         if ((rc = run_reduce_group(p, s, rt))) return rc;
         rt.nseg = 0; rt.nblocks = 0;
     }
+    const int64_t lo = l == 0 ? 0 : p->pix[l].ln1g, hi = stage == 0 ? p->total : p->pix[l + 1].ln1g;
+    if (g_off) *g_off = lo;
+    if (g_len) *g_len = hi - lo;
+    if (l > 0) return AFR_OK;
     // positional table: the sum over the batch of the gradient of the residual stream's first value (model.py:140-141 idiom)
     HIPCHK(afr_launch_reduce(p->G + p->px_pos, dh, B, (long long)T * d, (long long)T * d, 1.f, 0, s));
     HIPCHK(afr_launch_pixel_ctx_bwd((const float*)(p->ws + p->o_dctx), p->last_x, p->last_font, B, d, c.vocab, c.n_fonts, p->G + p->px_emb,
@@ -1052,12 +1061,7 @@ static int backward_stage_impl(afr_plan* p, int stage, int64_t* g_off, int64_t* 
     local_rt.nseg = 0; local_rt.nblocks = 0; local_rt.adam = 0;
     RTable& rt = shared_rt ? *shared_rt : local_rt;
     auto flush = [&]() -> int { return shared_rt ? AFR_OK : run_reduce_group(p, s, rt); };
-    if (c.kind == AFR_KIND_PIXEL) {        // one stage: the whole reverse pass (its slab reductions are flushed per block inside)
-        if ((rc = pixel_backward(p, s))) return rc;
-        if (g_off) *g_off = 0;
-        if (g_len) *g_len = p->total;
-        return AFR_OK;
-    }
+    if (c.kind == AFR_KIND_PIXEL) return pixel_backward(p, s, stage, g_off, g_len);     // (its slab reductions are flushed per stage inside)
     if (c.kind == AFR_KIND_SHEET) {
         const int Kz = c.max_length * c.fc_dim;
         void* z = p->ws + p->o_z;
@@ -1198,7 +1202,7 @@ static int backward_stage_impl(afr_plan* p, int stage, int64_t* g_off, int64_t* 
 
 extern "C" int afr_backward_stages(const afr_plan* p) {
     if (!p) return 0;
-    if (p->cfg.kind == AFR_KIND_PIXEL) return 1;
+    if (p->cfg.kind == AFR_KIND_PIXEL) return p->cfg.n_hidden;
     return p->cfg.kind == AFR_KIND_SHEET ? 2 : (int)p->layers.size();
 }
 

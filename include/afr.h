@@ -30,7 +30,7 @@ enum { AFR_KIND_SHEET = 0,   /* AttentionFontRenderer, model.py:129-204         
        AFR_KIND_GLYPH = 1,   /* per-glyph MLP (BASELINE.json configs C1-C4)                     */
        AFR_KIND_PIXEL = 2 }; /* per-pixel-token transformer (BASELINE.json configs[4]): embed_dim = d_model
                                 (<= 512, = 64 * heads), fc_dim = ff width, n_hidden = blocks, out_h * out_w = pixel tokens.
-                                Every entry point serves it; afr_backward_stages() = 1 (the reverse pass is one stage).   */
+                                Every entry point serves it; one backward stage per block, last block first.                */
 enum { AFR_F32 = 0,          /* exact-f32 MFMA everywhere: parity mode (<=1e-4 vs reference)     */
        AFR_BF16 = 1 };       /* bf16 MFMA operands, f32 accumulate, f32 master weights           */
 enum { AFR_TARGET_U8 = 0,    /* 8-bit pixels as stored in the BMPs; k/255.0f on device           */

@@ -20,11 +20,19 @@ def _glyph_engine(max_batch=512, dtype="f32"):
     return cfg, eng
 
 
-@pytest.mark.parametrize("kind", ["glyph", "sheet"])
+@pytest.mark.parametrize("kind", ["glyph", "sheet", "pixel"])
 def test_staged_backward_equals_monolithic_and_covers_the_buffer(kind):
     from ai_font_renderer_amd.engine import Engine
     from .util import SheetConfig
-    if kind == "glyph":
+    if kind == "pixel":                                       # one stage per block; stage 0 also the head, the last one the tables
+        from ai_font_renderer_amd.config import PixelConfig
+        cfg = PixelConfig(out_h=4, out_w=6, d_model=128, heads=2, layers=3, ff_dim=200, n_fonts=2)
+        eng = Engine(cfg, max_batch=16)
+        eng.load_params(synth.make_params(cfg))
+        assert eng.backward_stages == 3
+        args = dict(x=torch.from_numpy((32 + (np.arange(11) * 7) % 95).astype(np.int64)), font=torch.from_numpy((np.arange(11) % 2).astype(np.int64)),
+                    target=torch.from_numpy(synth.hash_u8(931, (11, 4, 6))))
+    elif kind == "glyph":
         cfg, eng = _glyph_engine()
         x, font, t = glyph_inputs(cfg, 300)
         args = dict(x=torch.from_numpy(x), target=torch.from_numpy(t), font=torch.from_numpy(font))
@@ -80,6 +88,38 @@ def test_data_parallel_stepper_over_rccl_world1(schedule, monkeypatch):
             st2.step(xt, tt, ft, mean_elems=300 * cfg.pixels)
         assert st2.global_loss() == l_dp
         assert torch.equal(eng2.flat_params, p_dp)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_pixel_transformer_through_the_data_parallel_step(monkeypatch):
+    """BASELINE configs[4]'s model (C5-mini, bf16) through the multi-rank code path with the overlapped schedule (stage 0's range
+    reduced asynchronously while the other blocks' stages run) over a world of one: the parameters of the single-GPU step."""
+    import torch.distributed as dist
+    from ai_font_renderer_amd import parallel
+    from ai_font_renderer_amd.config import C5_MINI as cfg
+    from ai_font_renderer_amd.engine import Engine
+    from ai_font_renderer_amd.parallel import DataParallelStepper
+    monkeypatch.setattr(parallel, "OVERLAP_MIN_BYTES", 0)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", str(29600 + os.getpid() % 300))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        B = 24
+        xt = torch.from_numpy((32 + (np.arange(B) * 11) % 95).astype(np.int64)).cuda()
+        ft = torch.from_numpy((np.arange(B) % 2).astype(np.int64)).cuda()
+        tt = torch.from_numpy(synth.hash_u8(932, (B, cfg.out_h, cfg.out_w))).cuda()
+        res = []
+        for world in (2, 1):
+            eng = Engine(cfg, dtype="bf16", max_batch=B)
+            eng.load_params(synth.make_params(cfg))
+            st = DataParallelStepper(eng, dist if world > 1 else None, world=world)
+            for _ in range(3):
+                st.step(xt, tt, ft, mean_elems=B * cfg.pixels, lr=1e-5)
+            res.append((st.global_loss(), eng.flat_params.clone()))
+            del eng
+        assert res[0][0] == res[1][0]
+        assert torch.equal(res[0][1], res[1][1])
     finally:
         dist.destroy_process_group()
 

@@ -81,7 +81,7 @@ def test_c5_mini_backward_and_adamw_trajectory_match_the_torch_nn_twin():
     lr = float(fx["lr"])
     eng = Engine(cfg, dtype="f32", max_batch=32)
     eng.load_params(synth.make_params(cfg))
-    assert eng.backward_stages == 1
+    assert eng.backward_stages == cfg.layers
     # forward -> loss -> backward through the separate entry points
     eng.forward(x, font, training=True, want_output=False)
     eng.loss_grad(tgt)
