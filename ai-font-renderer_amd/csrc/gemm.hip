@@ -333,8 +333,8 @@ __device__ __forceinline__ bf16x8 read_frag(const char* S, int xb, int ks, int l
 //   WM=4: 256x128, 512 threads, 3-stage LDS ring (144 KiB), tile t+2 in flight behind a COUNTED vmcnt and a raw
 //         s_barrier: the main loop was latency-bound on global->LDS with one tile in flight, and the bigger tile
 //         needs 25 % fewer DMA bytes per FLOP.
-// p/m/v accessors of the fused AdamW epilogue.  Loads are ordinary (non-temporal loads measured 4 % slower); stores are
-// streaming: the values are not read again before the next step (measured -1 % on the R0 dW kernel).
+// p/m/v accessors of the fused AdamW tails.  Stores are streaming: the values are not read again before the next step (measured
+// -1 % on the R0 dW kernel); the loads of wave_epilogue's tail are streaming buffer loads (see there), strip_finish's are ordinary.
 #define ADLD(ptr) (*reinterpret_cast<const float4*>(ptr))
 __device__ __forceinline__ void nt_st4(float* q, float4 v) {
     const f32x4 w = {v.x, v.y, v.z, v.w};
@@ -465,11 +465,22 @@ __device__ __forceinline__ void wave_epilogue_at(const GemmParams& p, const ACC&
         const int nf = nb0 + 4 * c4;
         const bool okc = nf < p.N;
         float4 qp[ADF], qm[ADF], qv[ADF];
+        // The optimizer state is read as STREAMING data (buffer loads with the nt bit): 3 GB of p/m/v pass through the L2s during
+        // R0's weight-gradient product, and without the hint they displace the operand slabs the 64 concurrent tiles of an XCD
+        // share (PMC: 2.37 GB fetched per launch against 1.47 GB of state + 52 MB of operands).  Measured on R0: 655 -> 602 us.
+        // (sc1 / sc0|sc1 instead: no change.  The addresses are tile-relative 32-bit offsets on a descriptor of the tile's origin.)
+        const size_t tile0 = (size_t)mb * p.ldc + nb0;
+        const bool adam_ld = ADAM && p.ad_p != nullptr;
+        const __amdgpu_buffer_rsrc_t rp_ = __builtin_amdgcn_make_buffer_rsrc((void*)(adam_ld ? p.ad_p + tile0 : nullptr), 0, 0x7FFFFFFF, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rm_ = __builtin_amdgcn_make_buffer_rsrc((void*)(adam_ld ? p.ad_m + tile0 : nullptr), 0, 0x7FFFFFFF, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rv_ = __builtin_amdgcn_make_buffer_rsrc((void*)(adam_ld ? p.ad_v + tile0 : nullptr), 0, 0x7FFFFFFF, 0x00020000);
         auto load_f = [&](int ps, int buf) {
             const int m = mb + ps * 4 + (lane >> 4);
             if (m < p.M && okc) {
-                const size_t wi = (size_t)m * p.ldc + nf;
-                qp[buf] = ADLD(p.ad_p + wi); qm[buf] = ADLD(p.ad_m + wi); qv[buf] = ADLD(p.ad_v + wi);
+                const unsigned vo = (unsigned)(((ps * 4 + (lane >> 4)) * p.ldc + 4 * c4) * 4);
+                qp[buf] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rp_, vo, 0, 2));
+                qm[buf] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rm_, vo, 0, 2));
+                qv[buf] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rv_, vo, 0, 2));
             }
         };
         const bool adam = ADAM && p.ad_p != nullptr;
@@ -742,6 +753,9 @@ __device__ __forceinline__ void gemm_bf16_body(const GemmParams& p, const int bi
     }
     const unsigned fpA = (ALAY == 0 ? 8u : 4u) * p.lda * 2, fpB = (BLAY == 0 ? 8u : 4u) * p.ldb * 2;     // bytes per piece step
     const unsigned ftA = ALAY == 0 ? 128u : 64u * p.lda * 2, ftB = BLAY == 0 ? 128u : 64u * p.ldb * 2;   // bytes per K-tile
+    // (Measured and dropped: the nt bit on the pieces of the operand that streams -- R0's 246 MB weight shadow.  Its tiles are
+    // shared by the row tiles running beside each other on the XCD, and marked streaming they leave the L2 before the last of
+    // those has read them: forward 283 -> 309 us, input gradient 304 -> 340 us.)
     auto dma_s = [&](i32x4 rsrc, unsigned lds_addr, unsigned voff, unsigned soff) {
         unsigned keep;
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 3\n\tbuffer_load_dwordx4 %1, %4, %3 offen lds\n\ts_mov_b32 m0, %0"
