@@ -60,10 +60,17 @@ class Engine:
     """One plan + its device buffers.  `params[name]` are views into the flat float32 buffer in
     state_dict order, so checkpoints interchange with the reference (helpers.py:76-105)."""
 
-    def __init__(self, cfg, dtype="f32", max_batch=1024, device=None, seed=42, rank=0, with_optimizer=True, flags=0):
+    def __init__(self, cfg, dtype="f32", max_batch=1024, device=None, seed=42, rank=0, with_optimizer=True, flags=0, micro_batch=None):
+        """micro_batch: train_step / forward_loss + backward of a batch larger than this many samples run as micro-steps of at
+        most that many, their gradients summed (gradient accumulation: the saved activations of BASELINE configs[4]'s 2048
+        glyphs per GPU would be 800 GB; 32 at a time they are 12.6 GB).  The plan is then sized for micro_batch, not max_batch."""
         if not torch.cuda.is_available():
             raise RuntimeError("ai_font_renderer_amd.Engine needs an MI355X: the hot path has no CPU fallback")
         self.lib = _lib.lib()
+        self.micro_batch = int(micro_batch) if micro_batch else None
+        if self.micro_batch:
+            max_batch = min(int(max_batch), self.micro_batch)
+        self._grad_acc = None
         self.cfg, self.dtype, self.max_batch = cfg, dtype, int(max_batch)
         self.seed, self.rank, self.flags = int(seed), int(rank), int(flags)
         self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
@@ -159,6 +166,10 @@ class Engine:
 
     def forward(self, x, font=None, training=False, step=0, want_output=True):
         x, font = self._prep_x(x, font)
+        if self.micro_batch and x.shape[0] > self.micro_batch:        # an inference forward of a large batch, micro_batch rows at a time
+            outs = [self.forward(x[lo:lo + self.micro_batch], None if font is None else font[lo:lo + self.micro_batch], training, step, want_output)
+                    for lo in range(0, x.shape[0], self.micro_batch)]
+            return torch.cat(outs) if want_output else None
         self.ensure_batch(x.shape[0])
         if isinstance(self.cfg, SheetConfig):
             if x.dim() != 2:
@@ -237,6 +248,8 @@ class Engine:
                    mean_elems=None, do_step=True):
         """zero_grad -> forward -> loss -> backward -> AdamW, one C call (model.py:292-310)."""
         x, font = self._prep_x(x, font)
+        if self.micro_batch and x.shape[0] > self.micro_batch:
+            return self._train_step_accumulated(x, target, font, step, lr, betas, eps, weight_decay, mean_elems, do_step)
         self.ensure_batch(x.shape[0])
         t, td = self._target(target)
         if isinstance(self.cfg, SheetConfig):
@@ -252,6 +265,28 @@ class Engine:
                                            int(bool(do_step)), lr, betas[0], betas[1], eps, weight_decay, max(self.t, 1))
         self._keep = (x, font)
         self._keep_t = t
+
+    def _train_step_accumulated(self, x, target, font, step, lr, betas, eps, weight_decay, mean_elems, do_step):
+        """Gradient accumulation: the batch in micro-steps of self.micro_batch samples (forward + loss + backward each, the loss
+        and its gradient scaled for the WHOLE batch through mean_elems), gradients summed in micro-step order, one AdamW step."""
+        B = x.shape[0]
+        me = int(mean_elems) if mean_elems is not None else B * self.pixels
+        t, _ = self._target(target)
+        if self._grad_acc is None:
+            self._grad_acc = torch.empty_like(self.flat_grads)
+        st = int(step if step is not None else self.t + (1 if do_step else 0))
+        for i, lo in enumerate(range(0, B, self.micro_batch)):
+            hi = min(B, lo + self.micro_batch)
+            # (models with dropout: micro-step i draws its masks from stream st * 65536 + i)
+            self.train_step(x[lo:hi], t[lo:hi], font=None if font is None else font[lo:hi], step=st * 65536 + i if step is None else st,
+                            mean_elems=me, do_step=False)
+            if i == 0:
+                self._grad_acc.copy_(self.flat_grads)
+            else:
+                self._grad_acc.add_(self.flat_grads)
+        self.flat_grads.copy_(self._grad_acc)
+        if do_step:
+            self.adamw_step(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
 
     def read_loss(self, reset=True):
         v = float(self.loss_accum.item())

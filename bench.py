@@ -43,7 +43,7 @@ DESCR = {
     "c2": "C2: 16x16 glyph MLP 32->256->256, batch 4096 (BASELINE configs[1])",
     "c1": "C1: 16x16 glyph MLP 32->256->256, fp32, batch 95 (BASELINE configs[0])",
     "r0": "R0: reference AttentionFontRenderer, 100 chars -> 80x240 sheet, batch 1024/GPU",
-    "c5": "C5 micro-batch: 64x64 per-pixel-token transformer (d_model 512, 8 heads, 4 blocks, ff 2048; DESIGN.md 8), bf16 operands, 32 glyphs = 131072 tokens/GPU (BASELINE configs[4] asks fp8 and 2048 glyphs/GPU)",
+    "c5": "C5 micro-batch: 64x64 per-pixel-token transformer (d_model 512, 8 heads, 4 blocks, ff 2048; DESIGN.md 8), bf16 operands, 32 glyphs = 131072 tokens per micro-step (BASELINE configs[4] asks fp8 and 2048 glyphs/GPU: --batch 2048 runs that shard as 64 accumulated micro-steps)",
 }
 DEFAULT_DTYPE = {"c3": "bf16", "c2": "bf16", "c1": "f32", "r0": "bf16", "c5": "bf16"}
 DEFAULT_STEPS = {"c3": (200, 20), "c2": (500, 50), "c1": (500, 50), "r0": (30, 5), "c5": (20, 3)}
@@ -195,7 +195,9 @@ def measure(name, dtype, B, K, W, rank, world, dist, with_roofline=True, want_sa
     from ai_font_renderer_amd.engine import Engine
     from ai_font_renderer_amd.parallel import DataParallelStepper
     cfg = WORKLOADS[name]["cfg"]
-    eng = Engine(cfg, dtype=dtype, max_batch=B, rank=rank, flags=int(os.environ.get("AFR_ENGINE_FLAGS", "0")))   # kernel A/B runs
+    # (the pixel transformer above its workload's micro-batch: gradient accumulation, micro-batch rows at a time)
+    micro = WORKLOADS[name]["batch"] if (isinstance(cfg, PixelConfig) and B > WORKLOADS[name]["batch"]) else None
+    eng = Engine(cfg, dtype=dtype, max_batch=B, rank=rank, flags=int(os.environ.get("AFR_ENGINE_FLAGS", "0")), micro_batch=micro)   # flags: kernel A/B runs
     eng.load_params(synth.make_params(cfg))                           # same formula-generated weights on every rank
     x, font, tgt = make_inputs(name, cfg, B, rank)
     x, tgt = x.cuda(), tgt.cuda()

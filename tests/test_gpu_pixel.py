@@ -155,3 +155,34 @@ def test_c5_backward_other_shapes_and_bf16_vs_the_oracle():
         assert eng.error_flags() == 0
 
 
+
+
+def test_gradient_accumulation_over_micro_batches_equals_the_whole_batch():
+    """Engine(micro_batch=m): a batch of B > m samples runs as micro-steps of m (the last one shorter) whose gradients are summed
+    -- how BASELINE configs[4]'s 2048 glyphs per GPU fit.  Loss and gradients equal the one-pass step of the whole batch up to
+    the order of the f32 sums; two optimizer steps stay together."""
+    from ai_font_renderer_amd.config import C5_MINI as cfg
+    from ai_font_renderer_amd.engine import Engine
+    B = 27
+    rng = np.random.default_rng(9)
+    x = torch.from_numpy((32 + (np.arange(B) * 11) % 95).astype(np.int64))
+    font = torch.from_numpy((np.arange(B) % 2).astype(np.int64))
+    tgt = torch.from_numpy(rng.integers(0, 256, (B, cfg.out_h, cfg.out_w), dtype=np.uint8))
+    whole = Engine(cfg, dtype="f32", max_batch=B)
+    acc = Engine(cfg, dtype="f32", max_batch=B, micro_batch=8)
+    assert acc.max_batch == 8
+    for e in (whole, acc):
+        e.load_params(synth.make_params(cfg))
+        e.train_step(x, tgt, font=font, do_step=False)
+    lw, la = whole.read_loss(), acc.read_loss()
+    assert abs(lw - la) < 1e-6 * lw
+    for n, _ in cfg.param_shapes():
+        ref = whole.grads[n].cpu().numpy()
+        assert maxabs(acc.grads[n].cpu().numpy(), ref) <= 2e-5 * max(float(np.abs(ref).max()), 1e-12), n
+    for e in (whole, acc):
+        for _ in range(2):
+            e.train_step(x, tgt, font=font, lr=1e-5)
+    assert abs(whole.read_loss() - acc.read_loss()) < 1e-5
+    assert acc.t == whole.t == 2
+    # inference forward of the large batch, micro_batch rows at a time
+    assert maxabs(acc.forward(x, font).cpu().numpy(), whole.forward(x, font).cpu().numpy()) < 2e-5
