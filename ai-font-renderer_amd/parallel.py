@@ -102,7 +102,9 @@ class DataParallelStepper:
             return
         opt = {k: v for k, v in hyper.items() if k in ("lr", "betas", "eps", "weight_decay")}
         stages = getattr(eng, "backward_stages", 0)
-        if stages and eng.flat_grads.numel() * 4 >= OVERLAP_MIN_BYTES and not self.sharded():
+        mb = getattr(eng, "micro_batch", None)
+        accumulating = bool(mb) and x.shape[0] > mb          # gradient accumulation: the sum exists only after the last micro-step
+        if stages and eng.flat_grads.numel() * 4 >= OVERLAP_MIN_BYTES and not self.sharded() and not accumulating:
             # Backward runs last layer first.  Two collectives per step: the last layer's gradient range (half of the
             # bytes in the glyph nets, 99.98 % in the sheet model) is all-reduced ASYNCHRONOUSLY as soon as stage 0 has
             # produced it and overlaps the rest of the backward pass; everything else is one contiguous range
