@@ -157,6 +157,11 @@ static_assert(AFR_RT_MAXSEG >= 2 * AFR_MAX_HIDDEN + 2 * AFR_L1F_MAX_SPLIT + 4, "
 #define AFR_SPLITK_TARGET 512
 #endif
 static int choose_splitk(int M, int N, int K) {
+    // a small weight gradient reduced over very many rows (the pixel transformer's: 131072 token rows into 2048 x 512): as many
+    // K-slices as make the 256x256 tiles fill the chip exactly once -- the launcher then takes the 256x256 body for it
+    // (gemm.hip bf16_use_body256; measured 323 -> 292 us and 287 -> 246 us against the best split of the 256x128 ring)
+    const int t256 = ((M + 255) / 256) * ((N + 255) / 256);
+    if (K >= 32768 && t256 >= 8 && t256 <= 64 && 256 % t256 == 0 && K / (256 / t256) >= 1024) return 256 / t256;
     const int tiles = ((M + 127) / 128) * ((N + 127) / 128);
     int s = (AFR_SPLITK_TARGET + tiles - 1) / tiles;
     const int maxs = K / 256 > 0 ? K / 256 : 1;

@@ -1790,8 +1790,12 @@ static bool bf16_use_wide(const GemmParams& p) {
 // faster than the 256x128 ring (K = 512: 466 -> 390 us forward, 104 -> 87 us input gradient; K = 2048: 322 -> 266 us).
 static bool bf16_use_body256(const GemmParams& p) {
     static const int off = getenv("AFR_GEMM_NO_BODY256") ? atoi(getenv("AFR_GEMM_NO_BODY256")) : 0;      // kernel A/B measurements
-    if (off || p.splitk != 1 || p.mse_target || p.ad_p || p.colsum || p.a_rowmap || p.b_rowmap || p.coop_ws || p.fix_ws) return false;
+    if (off || p.mse_target || p.ad_p || p.a_rowmap || p.b_rowmap || p.coop_ws || p.fix_ws) return false;
     const long long t = (long long)((p.M + 255) / 256) * ((p.N + 255) / 256);
+    // weight gradients (both operands k-strided, split-K slabs): when the slices of the 256x256 tiles make whole rounds of the chip
+    const bool kk = (p.flags & AFR_GEMM_A_KSTRIDED) && (p.flags & AFR_GEMM_B_KSTRIDED);
+    if (kk && p.splitk > 1) return (t * p.splitk) % 256 == 0 && p.K / p.splitk >= 1024;
+    if (p.splitk != 1 || p.colsum) return false;
     static const int kmin = getenv("AFR_GEMM_BODY256_KMIN") ? atoi(getenv("AFR_GEMM_BODY256_KMIN")) : 256;
     return t >= 1024 && p.K >= kmin;
 }
@@ -1928,7 +1932,7 @@ hipError_t afr_launch_gemm(int dtype, const GemmParams& p_in, hipStream_t s) {
         if (bf16_use_body256(p)) {
             bf16k::GemmGroup g;
             g.n = 1; g.p[0] = p; g.blk0[0] = 0;
-            g.blk0[1] = ((p.M + 255) / 256) * ((p.N + 255) / 256);
+            g.blk0[1] = ((p.M + 255) / 256) * ((p.N + 255) / 256) * p.splitk;
             hipLaunchKernelGGL(bf16k::gemm_bf16_group256, dim3(g.blk0[1]), dim3(512), 0, s, g);
             return hipGetLastError();
         }
