@@ -431,7 +431,15 @@ __device__ __forceinline__ void wave_epilogue_at(const GemmParams& p, const ACC&
     // up front: one memory latency instead of eight serial ones
     bf16x8 auxv[8];
     uint2 tu8[8];
-    if (relu_mask || (mse && p.mse_target_dtype == AFR_TARGET_U8)) {
+    // ReLU gate as bits (mask_in, one byte per 8 columns): the 64 rows x 8 bytes of the wave's tile are ONE 8-byte load per lane
+    // (lane l: row mb + l), handed to the lane that owns (row, 8-column group) in each pass by two wave shuffles -- as 8 byte loads
+    // per lane the dX products of the pixel transformer spent 15 us of a 30 us workgroup life in this tail.  Needs 8-byte aligned
+    // rows (ldmask % 8 == 0, i.e. N % 64 == 0); otherwise the byte loads below.
+    const bool wide_bits = ALAY == 0 && relu_mask && p.mask_in && out_bf16 && (p.ldmask & 7) == 0;      // (ALAY == 1: weight gradients, no gate)
+    uint2 mrow = {0u, 0u};
+    if (wide_bits && mb + lane < p.M && nb0 < p.N)
+        mrow = *reinterpret_cast<const uint2*>(p.mask_in + (size_t)(mb + lane) * p.ldmask + (nb0 >> 3));
+    if ((relu_mask && !wide_bits) || (mse && p.mse_target_dtype == AFR_TARGET_U8)) {
         int am[8];                                   // aux rows (gathered through aux_rowmap when the mask operand is a table)
 #pragma unroll
         for (int ps = 0; ps < 8; ++ps) {
@@ -442,7 +450,7 @@ __device__ __forceinline__ void wave_epilogue_at(const GemmParams& p, const ACC&
         for (int ps = 0; ps < 8; ++ps) {
             const int m = mb + ps * 8 + (lane >> 3);
             if (m < p.M && ncol) {
-                if (relu_mask) {
+                if (relu_mask && !wide_bits) {
                     if (p.mask_in) auxv[ps][0] = __builtin_bit_cast(bf16_t, (unsigned short)p.mask_in[(size_t)m * p.ldmask + (n >> 3)]);   // the 8 bits travel in element 0
                     else auxv[ps] = *reinterpret_cast<const bf16x8*>(aux + (size_t)am[ps] * p.ldaux + n);
                 }
@@ -530,11 +538,16 @@ __device__ __forceinline__ void wave_epilogue_at(const GemmParams& p, const ACC&
         float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 #pragma unroll
         for (int r = 0; r < 8; ++r) { v[r] = rowbias ? v[r] + bia[r] : v[r]; v[r] = relu ? fmaxf(v[r], 0.f) : v[r]; }
+        unsigned wbits = 0;
+        if (wide_bits) {                                 // (shuffles before the divergent `continue`: every lane takes part)
+            const unsigned lo_w = (unsigned)__shfl((int)mrow.x, rl, 64), hi_w = (unsigned)__shfl((int)mrow.y, rl, 64);
+            wbits = ((c8 < 4 ? lo_w : hi_w) >> (8 * (c8 & 3))) & 0xFFu;
+        }
         const int m = mb + rl;
         if (m >= p.M || !ncol) continue;
         if (relu_mask) {
             if (p.mask_in) {
-                const unsigned bits = __builtin_bit_cast(unsigned short, auxv[ps][0]);
+                const unsigned bits = wide_bits ? wbits : (unsigned)__builtin_bit_cast(unsigned short, auxv[ps][0]);
 #pragma unroll
                 for (int r = 0; r < 8; ++r) v[r] = ((bits >> r) & 1u) ? v[r] : 0.f;
             } else {
