@@ -280,11 +280,9 @@ class Engine:
             # (models with dropout: micro-step i draws its masks from stream st * 65536 + i)
             self.train_step(x[lo:hi], t[lo:hi], font=None if font is None else font[lo:hi], step=st * 65536 + i if step is None else st,
                             mean_elems=me, do_step=False)
-            if i == 0:
-                self._grad_acc.copy_(self.flat_grads)
-            else:
-                self._grad_acc.add_(self.flat_grads)
-        self.flat_grads.copy_(self._grad_acc)
+            # acc (+)= this micro-step's gradient, by the library's own slab-sum kernel (fixed order: micro-step by micro-step)
+            self._call(self.lib.afr_op_reduce, _ptr(self._grad_acc), _ptr(self.flat_grads), 1, self.n_flat, self.n_flat, 1.0, int(i > 0))
+        self._call(self.lib.afr_op_reduce, _ptr(self.flat_grads), _ptr(self._grad_acc), 1, self.n_flat, self.n_flat, 1.0, 0)
         if do_step:
             self.adamw_step(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
 
