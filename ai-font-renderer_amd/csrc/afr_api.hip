@@ -310,7 +310,7 @@ extern "C" int afr_plan_create(const afr_config* c, afr_plan** out) {
         if (c->n_hidden == 1 && afr_glyph1_eligible(E, c->hidden[0], Pix, c->vocab, c->n_fonts) &&
             afr_glyph1_lds_bytes(c->dtype, E, c->hidden[0], Pix, c->vocab + c->n_fonts) <= 160 * 1024) {
             p->fused1 = true;
-            const size_t nblk = (B + afr_glyph1_rows(c->dtype) - 1) / afr_glyph1_rows(c->dtype);
+            const size_t nblk = (size_t)afr_glyph1_max_blocks(c->dtype, (int)B, Pix);      // row blocks x column split
             p->o_slab1 = carve(nblk * (size_t)p->total * sizeof(float));
             p->o_loss = carve((1040 + nblk + 64) * sizeof(float));           // room for one loss partial per block
             if (c->dtype == AFR_BF16) {
@@ -1371,13 +1371,27 @@ static int glyph1_fused(afr_plan* p, const int64_t* x, const int64_t* font, cons
     float* scratch = (float*)(p->ws + p->o_loss);
     a.inv_n = (float)(1.0 / (double)mean_elems); a.loss_partial = scratch + 1040; a.counter = reinterpret_cast<unsigned*>(scratch + 1032);
     a.loss_accum = loss_accum; a.err = (uint32_t*)(p->ws + p->o_err);
-    const int R = afr_glyph1_rows(c.dtype), nblk = (B + R - 1) / R;
+    const int R = afr_glyph1_rows(c.dtype), nrb = (B + R - 1) / R, cs = afr_glyph1_colsplit(c.dtype, B, Pix), nblk = nrb * cs;
+    a.cs = cs;
     {
         const double fl = 6.0 * B * ((double)E * N1 + (double)N1 * Pix);
         ProfScope ps(p, s, b16 ? "glyph1_step<bf16>" : "glyph1_step<f32>", fl, (double)nblk * p->total * 4.0 + (double)B * Pix);
         HIPCHK(afr_launch_glyph1_step(c.dtype, a, s));
     }
     for (const Tensor& tn : p->params) {
+        if (cs > 1 && (tn.off == l2.w_off || tn.off == l2.b_off)) {
+            // fc_output's rows are split over the cs blocks of a row block: block (rb, pc) holds rows [pc, pc + 1) * Pix / cs, so
+            // each row range is its own segment over the slabs rb * cs + pc
+            const long long per = tn.off == l2.w_off ? (long long)(Pix / cs) * N1 : Pix / cs;
+            for (int pc = 0; pc < cs; ++pc) {
+                afr_rtable_add(rt, p->G + tn.off + pc * per, a.slabs + (size_t)pc * p->total + tn.off + pc * per, nrb, (long long)cs * p->total, per);
+                if (b16 && tn.off == l2.w_off && rt.nseg > 0 && !rt.overflow) {
+                    RSeg& sg = rt.seg[rt.nseg - 1];
+                    sg.shT = (bf16_t*)(p->ws + p->o_w2t) + (size_t)pc * (Pix / cs); sg.tN = Pix; sg.tK = N1;      // columns pc * Pix / cs .. of W2^T [N1][Pix]
+                }
+            }
+            continue;
+        }
         afr_rtable_add(rt, p->G + tn.off, a.slabs + tn.off, nblk, p->total, (tn.numel + 3) / 4 * 4);
         // when the optimizer runs inside this reduce, it also keeps the transposed operand copies current
         if (b16 && rt.nseg > 0 && !rt.overflow) {

@@ -266,8 +266,11 @@ struct Glyph1Args {
     float* slabs; long long slab_stride;     // slab b: this block's partial gradients, flat-buffer layout
     long long o_emb, o_font, o_w1, o_b1, o_w2, o_b2;
     float inv_n; float* loss_partial; unsigned* counter; float* loss_accum; uint32_t* err;
+    int cs = 1;                              // column split: cs blocks share a row block, each owning P / cs output columns
 };
 int afr_glyph1_rows(int dtype);
+int afr_glyph1_colsplit(int dtype, int B, int P);     // blocks per row block (1, 2 or 4) for a batch of B
+int afr_glyph1_max_blocks(int dtype, int max_batch, int P);   // the most blocks any batch <= max_batch launches (slab / loss-partial count)
 bool afr_glyph1_eligible(int E, int N1, int P, int vocab, int n_fonts);
 size_t afr_glyph1_lds_bytes(int dtype, int E, int N1, int P, int table_rows);
 hipError_t afr_launch_transpose_bf16(const float* W, bf16_t* WT, int N, int K, hipStream_t s);

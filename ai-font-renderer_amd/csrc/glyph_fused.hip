@@ -1,6 +1,11 @@
 // glyph_fused.hip -- the launch-bound glyph nets (BASELINE configs[0] / [1]: embedding -> Linear(32,256) + ReLU ->
 // Linear(256,256) -> clamp, 78 K parameters) as ONE kernel per training step plus the grouped slab reduction.
 //
+// (Round 3: a row block may be shared by cs = 2 or 4 workgroups, each owning P / cs OUTPUT COLUMNS -- the batch of these
+// configs leaves most CUs idle (C1: 6 row blocks, C2: 64), and everything after the loss is linear in du: a workgroup computes
+// fc1 for its rows in full, then its columns of u / loss / du, its rows of dW2 / db2, and its PART of dh1 = du . W2 (the
+// reduction over its own columns only), from which dW1, db1 and the table rows follow as partial sums that the grouped reduce
+// adds over all cs * row-block slabs in block order.)
 // Every sample is independent up to the weight gradients, so a workgroup takes a block of R batch rows through the WHOLE
 // step -- gather (reference model.py:136,167), fc1 + ReLU (:148,183), fc_output (:152,196), clamp + MSE + d(loss)/du
 // (:156,268-270), and the backward of all of it (:309) -- with every activation of those rows resident in LDS, and
@@ -175,7 +180,9 @@ __global__ __launch_bounds__(MM<T>::NTH) void glyph1_step_kernel(Glyph1Args a) {
     T* h1T = h1 + R * ldN;
     T* du = h1T + N1 * ldR;
     T* duT = du + R * ldP;
-    const int b0 = blockIdx.x * R;
+    const int cs = a.cs, rb = (int)blockIdx.x / cs, pc = (int)blockIdx.x - rb * cs;
+    const int npt = P / 16 / cs, pt0 = pc * npt;       // this block's output-column tiles [pt0, pt0 + npt)
+    const int b0 = rb * R;
     const int nb = min(R, a.B - b0);
     // every target this wave's loss tiles will need (P <= 256: at most TPW tiles of MT x 4 pixels per lane), requested now:
     // they arrive under the gather and fc1 (asked for when a tile's MFMAs start, each tile waited ~1.5 us for them)
@@ -183,8 +190,8 @@ __global__ __launch_bounds__(MM<T>::NTH) void glyph1_step_kernel(Glyph1Args a) {
     float tv[TPW][MT][4];
 #pragma unroll
     for (int it = 0; it < TPW; ++it) {
-        const int pcol = (wave + it * NW) * 16 + r;
-        if (pcol < P) {
+        const int pcol = (pt0 + wave + it * NW) * 16 + r;
+        if (wave + it * NW < npt) {
 #pragma unroll
             for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -202,6 +209,7 @@ __global__ __launch_bounds__(MM<T>::NTH) void glyph1_step_kernel(Glyph1Args a) {
 #define G1STAMP() do { } while (0)
 #endif
     G1STAMP();
+    // (plain stores: streaming ones made this kernel 2 us shorter and the reduce, which then reads the slabs from HBM, 3 us longer)
     float* slab = a.slabs + (size_t)blockIdx.x * a.slab_stride;
 
     const T* W1 = reinterpret_cast<const T*>(a.W1);
@@ -241,7 +249,8 @@ __global__ __launch_bounds__(MM<T>::NTH) void glyph1_step_kernel(Glyph1Args a) {
 
     // ---- pre1 = h0 . W1^T + b1 ; h1 = relu(pre1)            wave w owns column tiles w, w+4, ...
     float bias_v = 0.f;
-    if constexpr (PF) first_tile<T>(ftB, P / 16, N1 / KB, wave, loadW2);   // fc_output's first tile arrives under fc1
+    auto loadW2o = [&](int nt, int kb) { return loadW2(pt0 + nt, kb); };      // (tile indices below are relative to pt0)
+    if constexpr (PF) first_tile<T>(ftB, npt, N1 / KB, wave, loadW2o);   // fc_output's first tile arrives under fc1
     rows_times_global<T, MT, NW>(h0, ldE, N1 / 16, E / KB, wave, r, q, loadW1,
         [&](int nt) { bias_v = a.b1[nt * 16 + r]; },
         [&](int nt, const f32x4 (&acc)[MT]) {
@@ -260,8 +269,8 @@ __global__ __launch_bounds__(MM<T>::NTH) void glyph1_step_kernel(Glyph1Args a) {
     // ---- u = h1 . W2^T + b2 ; clamp, MSE, du (rows past the batch contribute nothing)
     float lsum = 0.f;
     const float g2 = 2.f * a.inv_n;
-    rows_times_global_u<T, MT, NW, TPW>(h1, ldN, P / 16, N1 / KB, wave, r, q, loadW2,
-        [&](int nt, int) { bias_v = a.b2[nt * 16 + r]; },
+    rows_times_global_u<T, MT, NW, TPW>(h1, ldN, npt, N1 / KB, wave, r, q, loadW2o,
+        [&](int nt, int) { bias_v = a.b2[(pt0 + nt) * 16 + r]; },
         [&](int nt, int it, const f32x4 (&acc)[MT]) {
             const float bias = bias_v;
 #pragma unroll
@@ -278,22 +287,23 @@ __global__ __launch_bounds__(MM<T>::NTH) void glyph1_step_kernel(Glyph1Args a) {
                     lsum += live ? diff * diff : 0.f;
                     v[i] = (live && u >= 0.f && u <= 1.f) ? g2 * diff : 0.f;
                 }
-                put_both(du, ldP, duT, ldR, m * 16, nt * 16, v);
+                put_both(du, ldP, duT, ldR, m * 16, (pt0 + nt) * 16, v);
             }
         }, PF ? &ftB : nullptr);
     __syncthreads();
     G1STAMP();   // 2: P2 + loss
     // dh1's first W2^T tile is requested now and arrives under the dW2 phase (which reads LDS only)
     const T* W2T = reinterpret_cast<const T*>(a.W2T);
+    const int kb0 = pt0 * 16 / KB, nkbp = npt * 16 / KB;          // this block's k-blocks of the reduction over P (npt * 16 is a multiple of KB)
     auto loadW2T = [&](int nt, int kb) {
-        if constexpr (sizeof(T) == 4) return gather16(reinterpret_cast<const float*>(a.W2T), N1, nt * 16 + r, kb, q);
-        else return ld16(W2T, P, nt * 16 + r, kb, q);
+        if constexpr (sizeof(T) == 4) return gather16(reinterpret_cast<const float*>(a.W2T), N1, nt * 16 + r, kb0 + kb, q);
+        else return ld16(W2T, P, nt * 16 + r, kb0 + kb, q);
     };
-    if constexpr (PF) first_tile<T>(ftA, N1 / 16, P / KB, wave, loadW2T);
+    if constexpr (PF) first_tile<T>(ftA, N1 / 16, nkbp, wave, loadW2T);
 
     // ---- dW2[p][k] = sum_b du[b][p] h1[b][k]  (+ db2): wave w owns p tiles w, w+4, ...; 4 k tiles at a time
     // (operands swapped: the tile comes out as [k][p], so a lane holds 4 consecutive k of one row p -> one 16-byte store)
-    for (int pt = wave; pt < P / 16; pt += NW) {
+    for (int pt = pt0 + wave; pt < pt0 + npt; pt += NW) {
         for (int kc = 0; kc < N1 / 64; ++kc) {
             f32x4 acc[4];
 #pragma unroll
@@ -309,7 +319,7 @@ __global__ __launch_bounds__(MM<T>::NTH) void glyph1_step_kernel(Glyph1Args a) {
                 *reinterpret_cast<f32x4*>(slab + a.o_w2 + (size_t)(pt * 16 + r) * N1 + kc * 64 + j * 16 + 4 * q) = acc[j];
         }
     }
-    for (int pp = tid; pp < P; pp += NT) {
+    for (int pp = pt0 * 16 + tid; pp < (pt0 + npt) * 16; pp += NT) {
         float s = 0.f;
         for (int b = 0; b < R; ++b) s += (float)duT[pp * ldR + b];
         slab[a.o_b2 + pp] = s;
@@ -317,8 +327,9 @@ __global__ __launch_bounds__(MM<T>::NTH) void glyph1_step_kernel(Glyph1Args a) {
     __syncthreads();                     // every wave is done reading h1T (dW2) before dpre1 overwrites it below
     G1STAMP();   // 3: dW2 + db2
 
-    // ---- dh1 = du . W2 ; dpre1 = dh1 * [h1 > 0], written over h1 / h1T (each element is read and rewritten by its owner only)
-    rows_times_global<T, MT, NW>(du, ldP, N1 / 16, P / KB, wave, r, q, loadW2T,
+    // ---- dh1 = du . W2 (over this block's columns: a partial sum when cs > 1) ; dpre1 = dh1 * [h1 > 0], written over h1 / h1T
+    // (each element is read and rewritten by its owner only)
+    rows_times_global<T, MT, NW>(du + pt0 * 16, ldP, N1 / 16, nkbp, wave, r, q, loadW2T,
         [](int) {},
         [&](int nt, const f32x4 (&acc)[MT]) {
 #pragma unroll
@@ -418,6 +429,24 @@ __global__ __launch_bounds__(256) void transpose_bf16_kernel(const float* __rest
 }
 
 int afr_glyph1_rows(int dtype) { return dtype == AFR_BF16 ? MM<bf16_t>::R : MM<float>::R; }
+// Blocks per row block: as many (4, 2, 1) as keep the launch within one round of the chip, with whole k-blocks of the
+// dh1 reduction per block (P / cs a multiple of 32 bf16 / 16 f32 elements).  AFR_G1_CS overrides (kernel A/B measurements).
+int afr_glyph1_colsplit(int dtype, int B, int P) {
+    static const int force = getenv("AFR_G1_CS") ? atoi(getenv("AFR_G1_CS")) : 0;
+    const int R = afr_glyph1_rows(dtype), kb = dtype == AFR_BF16 ? MM<bf16_t>::KB : MM<float>::KB, nrb = (B + R - 1) / R;
+    int cs = force > 0 ? force : 4;
+    while (cs > 1 && ((P / cs) % kb != 0 || (P / 16) % cs != 0 || (force <= 0 && nrb * cs > 256))) cs >>= 1;
+    return cs;
+}
+int afr_glyph1_max_blocks(int dtype, int max_batch, int P) {
+    const int R = afr_glyph1_rows(dtype), nrb = (max_batch + R - 1) / R;
+    int m = nrb * afr_glyph1_colsplit(dtype, max_batch, P);
+    // a smaller batch may split further: at most 4 blocks per row block, and (unless forced) never more than 256 blocks then
+    const int alt = nrb * 4 < 256 ? nrb * 4 : 256;
+    if (alt > m) m = alt;
+    if (getenv("AFR_G1_CS")) m = nrb * 4;
+    return m;
+}
 bool afr_glyph1_eligible(int E, int N1, int P, int vocab, int n_fonts) {
     return E % 32 == 0 && E <= 64 && N1 % 64 == 0 && N1 <= 256 && P % 64 == 0 && P <= 256 && vocab + n_fonts <= 264;
 }
@@ -452,7 +481,8 @@ hipError_t afr_launch_glyph1_step(int dtype, const Glyph1Args& a, hipStream_t s)
         if (e != hipSuccess) return e;
         if (dev >= 0 && dev < 8) done[dev] = lds;
     }
-    const int nblk = (a.B + R - 1) / R;
+    if (a.cs < 1 || (a.P / 16) % a.cs) return hipErrorInvalidValue;
+    const int nblk = (a.B + R - 1) / R * a.cs;
     const int NTL = dtype == AFR_BF16 ? MM<bf16_t>::NTH : MM<float>::NTH;
     if (dtype == AFR_BF16) {
         if (u8) hipLaunchKernelGGL((glyph1_step_kernel<bf16_t, true>), dim3(nblk), dim3(NTL), lds, s, a);
