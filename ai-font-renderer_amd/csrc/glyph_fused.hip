@@ -180,6 +180,9 @@ __global__ __launch_bounds__(MM<T>::NTH) void glyph1_step_kernel(Glyph1Args a) {
     T* h1T = h1 + R * ldN;
     T* du = h1T + N1 * ldR;
     T* duT = du + R * ldP;
+#ifdef AFR_G1_DEBUG
+    const unsigned long long t_entry = __builtin_amdgcn_s_memrealtime();
+#endif
     const int cs = a.cs, rb = (int)blockIdx.x / cs, pc = (int)blockIdx.x - rb * cs;
     const int npt = P / 16 / cs, pt0 = pc * npt;       // this block's output-column tiles [pt0, pt0 + npt)
     const int b0 = rb * R;
@@ -403,7 +406,7 @@ __global__ __launch_bounds__(MM<T>::NTH) void glyph1_step_kernel(Glyph1Args a) {
     G1STAMP();   // 7: scatter + table store
 #ifdef AFR_G1_DEBUG
     if (blockIdx.x == 0 && tid == 0) {
-        printf("phases (us):");
+        printf("entry->first stamp %.2f us; phases (us):", (double)(tstamp[0] - t_entry) * 0.01);
         for (int i = 1; i < nst; ++i) printf(" %.2f", (double)(tstamp[i] - tstamp[i - 1]) * 0.01);
         printf("\n");
     }
@@ -418,6 +421,10 @@ __global__ __launch_bounds__(MM<T>::NTH) void glyph1_step_kernel(Glyph1Args a) {
 #pragma unroll
     for (int w = 0; w < NW; ++w) bsum += red[w];
     loss_block_finish(bsum, a.loss_partial, a.counter, a.loss_accum, a.inv_n, red + 16);
+#ifdef AFR_G1_DEBUG
+    if (blockIdx.x == 0 && tid == 0) printf("last stamp -> exit %.2f us; entry -> exit %.2f us\n", (double)(__builtin_amdgcn_s_memrealtime() - tstamp[nst - 1]) * 0.01,
+                                            (double)(__builtin_amdgcn_s_memrealtime() - t_entry) * 0.01);
+#endif
 }
 
 // W [N][K] f32 -> WT [K][N] bf16 (the transposed operand copies of the bf16 fused step)
