@@ -87,6 +87,7 @@ __global__ __launch_bounds__(256) void pixel_add_ln_kernel(const float* __restri
     const int lane = threadIdx.x & 63;
     const int c0 = 8 * lane;
     const bool live = c0 < d;
+    // (g, b stay per-row loads (cache hits): held in 16 registers across the row loop this kernel ran 7 % slower)
     for (long long r = blockIdx.x * 4ll + (threadIdx.x >> 6); r < rows; r += (long long)gridDim.x * 4) {
         float v[8];
 #pragma unroll
@@ -161,11 +162,19 @@ __global__ __launch_bounds__(256) void pixel_head_kernel(const float* __restrict
                                                          float* __restrict__ u, float* __restrict__ y, long long rows, int d, float eps) {
     const int lane = threadIdx.x & 63, c0 = 8 * lane;
     const bool live = c0 < d;
-    for (long long r = blockIdx.x * 4ll + (threadIdx.x >> 6); r < rows; r += (long long)gridDim.x * 4) {
-        float v[8], av[8];
+    float gv[8], bv[8], wv[8];                            // per-lane constants once; the next row is requested before this one is worked on
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = av[j] = 0.f;
-        if (live) { ld8v(hin + (size_t)r * d + c0, v); ld8v(add + (size_t)r * d + c0, av); }
+    for (int j = 0; j < 8; ++j) { gv[j] = live ? g[c0 + j] : 0.f; bv[j] = live ? b[c0 + j] : 0.f; wv[j] = live ? w_out[c0 + j] : 0.f; }
+    const float bo = b_out[0];
+    const long long stride = (long long)gridDim.x * 4;
+    long long r = blockIdx.x * 4ll + (threadIdx.x >> 6);
+    float v[8], av[8], vn[8], avn[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = av[j] = vn[j] = avn[j] = 0.f;
+    if (r < rows && live) { ld8v(hin + (size_t)r * d + c0, v); ld8v(add + (size_t)r * d + c0, av); }
+    for (; r < rows; r += stride) {
+        const long long rn = r + stride;
+        if (rn < rows && live) { ld8v(hin + (size_t)rn * d + c0, vn); ld8v(add + (size_t)rn * d + c0, avn); }
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] += av[j];
         if (live) {
@@ -173,15 +182,17 @@ __global__ __launch_bounds__(256) void pixel_head_kernel(const float* __restrict
             *reinterpret_cast<float4*>(hd) = make_float4(v[0], v[1], v[2], v[3]);
             *reinterpret_cast<float4*>(hd + 4) = make_float4(v[4], v[5], v[6], v[7]);
         }
-        row_layernorm(v, g, b, c0, d, eps, live);
+        row_layernorm_r(v, gv, bv, d, eps, live);
         float a = 0.f;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) a = live ? fmaf(v[j], w_out[c0 + j], a) : a;
-        a = wave_sum(a) + b_out[0];
+        for (int j = 0; j < 8; ++j) a = fmaf(v[j], wv[j], a);
+        a = wave_sum(a) + bo;
         if (lane == 0) {
             if (u) u[r] = a;
             if (y) y[r] = fminf(fmaxf(a, 0.f), 1.f);
         }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { v[j] = vn[j]; av[j] = avn[j]; }
     }
 }
 
