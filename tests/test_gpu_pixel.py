@@ -227,3 +227,37 @@ def test_full_width_block_with_32768_token_rows_takes_the_256x256_body_for_its_l
         bound = 1.5e-1 if n in ("positional_encoding", "layers.0.ln1.weight") else 8e-2 if n.endswith("bias") else 3e-2
         assert fro < bound, (n, fro)
     assert eng.error_flags() == 0
+
+
+def test_pixel_plan_limits_and_caller_side_loss():
+    """Shapes the plan refuses say so (never a silent wrong answer); the narrowest supported model (d_model 64, one head, one
+    block, 8 pixel tokens, one context token) runs; a caller-side loss enters through set_output_grad exactly like the fused MSE."""
+    from ai_font_renderer_amd.config import PixelConfig
+    from ai_font_renderer_amd.engine import Engine
+    for bad in (PixelConfig(d_model=576, heads=9), PixelConfig(d_model=256, heads=2), PixelConfig(ff_dim=100), PixelConfig(out_h=3, out_w=3)):
+        with pytest.raises(_lib.AfrError):
+            Engine(bad, dtype="f32", max_batch=2)
+    cfg = PixelConfig(out_h=2, out_w=4, d_model=64, heads=1, layers=1, ff_dim=8, n_fonts=0)
+    B = 3
+    x = torch.tensor([33, 90, 126])
+    tgt = torch.from_numpy(synth.hash_u8(934, (B, 2, 4)))
+    eng = Engine(cfg, dtype="f32", max_batch=B)
+    eng.load_params(synth.make_params(cfg))
+    eng.train_step(x, tgt, do_step=False)
+    P = tparams(cfg)
+    y, cache = oracle.pixel_forward(P, x, None, cfg)
+    loss, du = oracle.mse_loss_grad(cache["u"], tgt.float() / 255.0)
+    G = oracle.pixel_backward(P, cache, du, cfg)
+    assert abs(eng.read_loss() - float(loss)) < 1e-6
+    for n, _ in cfg.param_shapes():
+        ref = G[n].numpy()
+        assert maxabs(eng.grads[n].cpu().numpy(), ref) <= 2e-4 * max(float(np.abs(ref).max()), 1e-12), n
+    fused = {n: eng.grads[n].clone() for n, _ in cfg.param_shapes()}
+    # the same gradient from a loss the caller differentiates itself: dy = d(mse)/d(clamped output)
+    yy = eng.forward(x, training=True)
+    dy = (2.0 * (yy - tgt.cuda().float() / 255.0) / yy.numel()).reshape(B, -1)
+    eng.set_output_grad(dy)
+    eng.backward()
+    for n, _ in cfg.param_shapes():
+        assert maxabs(eng.grads[n].cpu().numpy(), fused[n].cpu().numpy()) <= 1e-6 * max(float(fused[n].abs().max()), 1e-12), n
+    assert eng.error_flags() == 0
