@@ -401,6 +401,17 @@ __device__ __forceinline__ void wave_epilogue_at(const GemmParams& p, const ACC&
     } else if (EARLYB) epilogue_bias(p, nb0, lane, bia);
     const bool relu = EARLYB && (flags & AFR_GEMM_RELU);
     const bool rowbias = EARLYB && (flags & AFR_GEMM_BIAS);
+    // the fused loss' uint8 targets of the wave's 8 row passes (8 bytes per lane and pass) are requested before the park as well
+    // (forward layout on the ring kernels only: the 256x256 body takes no fused loss)
+    uint2 tu8[8];
+    const bool early_t = EARLYB && pre_bias == nullptr && mse && p.mse_target_dtype == AFR_TARGET_U8;
+    if (early_t) {
+#pragma unroll
+        for (int ps = 0; ps < 8; ++ps) {
+            const int m = mb + ps * 8 + (lane >> 3);
+            if (m < p.M && ncol) tu8[ps] = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint8_t*>(p.mse_target) + (size_t)m * p.N + n);
+        }
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int ml = 16 * i + (lane & 15);
@@ -430,7 +441,6 @@ __device__ __forceinline__ void wave_epilogue_at(const GemmParams& p, const ACC&
     // the tails' global operands (aux for the ReLU mask, targets for the fused loss) are fetched for all 8 row passes
     // up front: one memory latency instead of eight serial ones
     bf16x8 auxv[8];
-    uint2 tu8[8];
     // ReLU gate as bits (mask_in, one byte per 8 columns): the 64 rows x 8 bytes of the wave's tile are ONE 8-byte load per lane
     // (lane l: row mb + l), handed to the lane that owns (row, 8-column group) in each pass by two wave shuffles -- as 8 byte loads
     // per lane the dX products of the pixel transformer spent 15 us of a 30 us workgroup life in this tail.  Needs 8-byte aligned
@@ -439,7 +449,7 @@ __device__ __forceinline__ void wave_epilogue_at(const GemmParams& p, const ACC&
     uint2 mrow = {0u, 0u};
     if (wide_bits && mb + lane < p.M && nb0 < p.N)
         mrow = *reinterpret_cast<const uint2*>(p.mask_in + (size_t)(mb + lane) * p.ldmask + (nb0 >> 3));
-    if ((relu_mask && !wide_bits) || (mse && p.mse_target_dtype == AFR_TARGET_U8)) {
+    if ((relu_mask && !wide_bits) || (mse && !early_t && p.mse_target_dtype == AFR_TARGET_U8)) {
         int am[8];                                   // aux rows (gathered through aux_rowmap when the mask operand is a table)
 #pragma unroll
         for (int ps = 0; ps < 8; ++ps) {
@@ -454,7 +464,7 @@ __device__ __forceinline__ void wave_epilogue_at(const GemmParams& p, const ACC&
                     if (p.mask_in) auxv[ps][0] = __builtin_bit_cast(bf16_t, (unsigned short)p.mask_in[(size_t)m * p.ldmask + (n >> 3)]);   // the 8 bits travel in element 0
                     else auxv[ps] = *reinterpret_cast<const bf16x8*>(aux + (size_t)am[ps] * p.ldaux + n);
                 }
-                if (mse) tu8[ps] = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint8_t*>(p.mse_target) + (size_t)m * p.N + n);
+                if (mse && !early_t) tu8[ps] = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint8_t*>(p.mse_target) + (size_t)m * p.N + n);
             }
         }
     }
