@@ -35,7 +35,13 @@ for w in c3 r0; do
   rocprofv3 --pmc SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 GRBM_GUI_ACTIVE -d $O/pmc_${w}_MFMA -o $w -- python3 bench.py --workload $w $B > $O/pmc_${w}_MFMA.log 2>&1
   echo "pmc $w MFMA done"
 done
-python3 tools/pmc_summary.py $O/pmc c3 r0 --json $O/pmc_traffic.json > $O/pmc_hbm_traffic.txt
+# the pixel transformer's micro-batch step: HBM traffic only (its launches are 10-100x longer: 10 steps)
+B5="--workload c5 --steps 10 --warmup 2 --no-extras --no-cpu-baseline --preheat-ms 0"
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $c -d $O/pmc_c5_$c -o c5 -- python3 bench.py $B5 > $O/pmc_c5_$c.log 2>&1
+  echo "pmc c5 $c done"
+done
+python3 tools/pmc_summary.py $O/pmc c3 r0 c5 --json $O/pmc_traffic.json > $O/pmc_hbm_traffic.txt
 python3 tools/pmc_mfma_summary.py $O/pmc c3 r0 > $O/pmc_mfma_busy.txt
 for w in c1 c2 c3 r0; do python3 tools/pmc_summary.py --stats $O/stats_$w > $O/${w}_kernel_stats.csv; done
 echo "profiles collected under $O"

@@ -44,6 +44,7 @@ def short(name):
     if m:
         return m.group(1).replace(" ", "")
     for k in ("sheet_bwd", "sheet_fwd", "adamw", "reduce_group", "reduce_slabs", "mse_grad", "glyph1_step", "glyph_l1_fwd", "glyph_l1_bwd_fused", "glyph_l1_bwd",
+              "pixel_ln_bwd", "pixel_add_ln", "pixel_attn_bwd", "pixel_attn", "pixel_head_bwd", "pixel_head", "pixel_ctx_bwd", "pixel_ctx", "pixel_accum", "pixel_cast",
               "glyph_table", "glyph_combo", "gemm_fp8", "f32_to_fp8", "glyph_embed_bwd", "glyph_embed", "transpose_bf16", "f32_to_bf16", "clamp_out", "clamp_bwd"):
         if k in name:
             return k
