@@ -1801,8 +1801,6 @@ static bool bf16_use_wide(const GemmParams& p) {
     // a fused-AdamW epilogue moves 26 B per output element and is the longer half of such a kernel; two 128x128 blocks
     // per CU (64 KiB of LDS each) let one block's epilogue run under the other's K loop, one 256x128 block cannot
     if (p.ad_p) return false;
-    static const int narrow_k = getenv("AFR_GEMM_NARROW_K") ? atoi(getenv("AFR_GEMM_NARROW_K")) : 0;     // kernel A/B measurements
-    if (narrow_k && p.K / p.splitk <= narrow_k) return false;
     const long long t = (long long)((p.M + 255) / 256) * ((p.N + 127) / 128) * p.splitk;
     // a wide grid that leaves CUs idle loses to the 128x128 kernel at two blocks per CU (R0 dX: 200 wide tiles 323 us,
     // 400 narrow ones 302 us); from a full round on the two run level and wide needs fewer L2->LDS bytes
@@ -1819,8 +1817,7 @@ static bool bf16_use_body256(const GemmParams& p) {
     const bool kk = (p.flags & AFR_GEMM_A_KSTRIDED) && (p.flags & AFR_GEMM_B_KSTRIDED);
     if (kk && p.splitk > 1) return (t * p.splitk) % 256 == 0 && p.K / p.splitk >= 1024;
     if (p.splitk != 1 || p.colsum) return false;
-    static const int kmin = getenv("AFR_GEMM_BODY256_KMIN") ? atoi(getenv("AFR_GEMM_BODY256_KMIN")) : 256;
-    return t >= 1024 && p.K >= kmin;
+    return t >= 1024 && p.K >= 256;
 }
 bool afr_gemm_wide_ok(int M, int N, int K) {
     GemmParams q;
