@@ -403,6 +403,33 @@ def pixel_twin():
     print("pixel_twin.npz losses", losses, "clamped-inside fraction", float(((fx["eval_y"] > 0) & (fx["eval_y"] < 1)).mean()))
 
 
+def pixel_twin_full():
+    """The FULL-SIZE configuration of BASELINE configs[4] (64x64 = 4096 pixel tokens, d_model 512, 8 heads, 4 blocks, ff 2048) on
+    three glyphs: eval bitmaps, training loss and every gradient of the torch.nn twin (small tensors in full, the large ones by
+    row sums, column sums and 2048 samples).  Pins what the miniature cannot reach: 4096 tokens per glyph, i.e. 16 chunks of the
+    attention backward's key/value sums, token counts beyond one tile of every product."""
+    from ai_font_renderer_amd.config import C5 as cfg
+    B = 3
+    x = np.array([40, 77, 105], dtype=np.int64)
+    font = np.array([0, 1, 1], dtype=np.int64)
+    tu8 = synth.hash_u8(961, (B, cfg.out_h, cfg.out_w))
+    xt, ft, tgt = torch.from_numpy(x), torch.from_numpy(font), torch.from_numpy(tu8.astype(np.float32) / 255.0)
+    tw = PixelTwin(cfg)
+    tw.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_params(cfg).items()})
+    fx = dict(x=x, font=font, target_u8=tu8)
+    tw.eval()
+    with torch.no_grad():
+        fx["eval_y"] = tw(xt, ft).numpy()
+    tw.train()
+    loss = F.mse_loss(tw(xt, ft), tgt)
+    loss.backward()
+    for n_, (k, p) in enumerate(tw.named_parameters()):
+        _summary(fx, "grad/" + k, p.grad.detach().numpy(), 7100 + n_)
+    fx["loss"] = np.float32(loss.item())
+    np.savez_compressed(os.path.join(OUT, "pixel_twin_full.npz"), **fx)
+    print("pixel_twin_full.npz loss", loss.item(), "clamped-inside fraction", float(((fx["eval_y"] > 0) & (fx["eval_y"] < 1)).mean()))
+
+
 def glyph_bitmaps():
     from ai_font_renderer_amd import datagen
     fonts = ["/root/reference/FiraCode-Retina.ttf", "/root/reference/Montserrat-Regular.ttf"]
@@ -616,7 +643,7 @@ def helpers_fx():
 
 if __name__ == "__main__":
     only = sys.argv[1:]
-    for fn in (glyph_ref1, glyph_twin, pixel_twin, glyph_bitmaps, train_loop, mini, helpers_fx, r0):
+    for fn in (glyph_ref1, glyph_twin, pixel_twin, pixel_twin_full, glyph_bitmaps, train_loop, mini, helpers_fx, r0):
         if not only or fn.__name__ in only:
             fn()
     if "cpu_step_times" in only:              # timing, not a parity fixture: only on request

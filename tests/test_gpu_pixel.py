@@ -261,3 +261,22 @@ def test_pixel_plan_limits_and_caller_side_loss():
     for n, _ in cfg.param_shapes():
         assert maxabs(eng.grads[n].cpu().numpy(), fused[n].cpu().numpy()) <= 1e-6 * max(float(fused[n].abs().max()), 1e-12), n
     assert eng.error_flags() == 0
+
+
+def test_c5_full_size_forward_and_gradients_match_the_torch_nn_twin():
+    """The FULL-SIZE model (4096 pixel tokens, 4 blocks) on the three glyphs of tests/golden/pixel_twin_full.npz, f32 mode: eval
+    bitmaps, loss and every gradient of the HIP path against the torch.nn twin directly (16 chunks of the attention backward's
+    key/value sums, every product many tiles tall)."""
+    from ai_font_renderer_amd.config import C5 as cfg
+    from ai_font_renderer_amd.engine import Engine
+    fx = load("pixel_twin_full.npz")
+    x, font, tgt = torch.from_numpy(fx["x"]), torch.from_numpy(fx["font"]), torch.from_numpy(fx["target_u8"])
+    eng = Engine(cfg, dtype="f32", max_batch=3)
+    eng.load_params(synth.make_params(cfg))
+    assert maxabs(eng.forward(x, font).cpu().numpy(), fx["eval_y"]) < 2e-5
+    eng.train_step(x, tgt, font=font, do_step=False)
+    assert abs(eng.read_loss() - float(fx["loss"])) < 1e-6
+    G = {n: eng.grads[n].cpu().numpy() for n, _ in cfg.param_shapes()}
+    fxg = {k: fx[k] for k in fx.files}
+    assert _check_against_twin(fxg, cfg, "grad/", G, 4e-3) == len(cfg.param_shapes())
+    assert eng.error_flags() == 0

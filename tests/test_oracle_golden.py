@@ -267,3 +267,28 @@ def test_pixel_transformer_oracle_matches_the_torch_nn_twin():
     # entries whose gradient is analytically zero (the key projection's bias and what hangs on it) get Adam steps of +-lr from
     # rounding noise, in either direction on either side: three steps of lr is the floor of any parameter comparison
     check("param3/", P, 2e-5, floor=3.2 * float(fx["lr"]))
+
+
+def test_pixel_transformer_oracle_matches_the_full_size_twin():
+    """The full-size configuration (4096 pixel tokens per glyph; tests/golden/pixel_twin_full.npz, make_golden.py pixel_twin_full,
+    three glyphs): eval bitmaps, loss and every gradient of the torch.nn twin against the explicit oracle."""
+    from ai_font_renderer_amd.config import C5 as cfg
+    fx = load("pixel_twin_full.npz")
+    x, font = torch.from_numpy(fx["x"]), torch.from_numpy(fx["font"])
+    tgt = torch.from_numpy(fx["target_u8"].astype(np.float32) / 255.0)
+    P = tparams(cfg)
+    y, cache = oracle.pixel_forward(P, x, font, cfg)
+    assert maxabs(y.numpy(), fx["eval_y"]) < 1e-5
+    loss, du = oracle.mse_loss_grad(cache["u"], tgt)
+    assert abs(float(loss) - float(fx["loss"])) < 1e-6
+    G = oracle.pixel_backward(P, cache, du, cfg)
+    for k in P:
+        got = G[k].numpy()
+        if "grad/" + k in fx:
+            ref = fx["grad/" + k]
+            assert maxabs(got, ref) <= 4e-3 * max(float(np.abs(ref).max()), 1e-12), k
+        else:
+            g2 = got.reshape(got.shape[0], -1)
+            for part, val, sc in (("rowsum", g2.sum(1), np.abs(g2).sum(1).max()), ("colsum", g2.sum(0), np.abs(g2).sum(0).max()),
+                                  ("samples", got.reshape(-1)[fx["grad/" + k + "/idx"]], np.abs(got).max())):
+                assert maxabs(val, fx[f"grad/{k}/{part}"]) <= 4e-3 * max(float(sc), 1e-12), (k, part)
