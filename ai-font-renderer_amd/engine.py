@@ -220,6 +220,9 @@ class Engine:
     def forward_loss(self, x, target, font=None, step=None, mean_elems=None):
         """Training forward with the loss/grad fused into the last layer's epilogue (no optimizer step)."""
         x, font = self._prep_x(x, font)
+        if self.micro_batch and x.shape[0] > self.micro_batch:
+            raise ValueError(f"forward_loss / backward work on one micro-batch (<= {self.micro_batch} samples); a batch of {x.shape[0]} "
+                             "accumulates through train_step")
         self.ensure_batch(x.shape[0])
         t, td = self._target(target)
         if isinstance(self.cfg, SheetConfig):
