@@ -124,6 +124,39 @@ def test_pixel_transformer_through_the_data_parallel_step(monkeypatch):
         dist.destroy_process_group()
 
 
+def test_accumulating_rank_through_the_data_parallel_step(monkeypatch):
+    """A rank whose batch exceeds its micro-batch (Engine(micro_batch=m): gradient accumulation) takes the plain schedule --
+    accumulate, one all-reduce of the summed gradient, AdamW -- whatever the overlap threshold says; world of one over RCCL,
+    equal to the same engine stepping by itself."""
+    import torch.distributed as dist
+    from ai_font_renderer_amd import parallel
+    from ai_font_renderer_amd.config import C5_MINI as cfg
+    from ai_font_renderer_amd.engine import Engine
+    from ai_font_renderer_amd.parallel import DataParallelStepper
+    monkeypatch.setattr(parallel, "OVERLAP_MIN_BYTES", 0)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", str(29600 + os.getpid() % 300))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        B = 20
+        xt = torch.from_numpy((32 + (np.arange(B) * 11) % 95).astype(np.int64)).cuda()
+        ft = torch.from_numpy((np.arange(B) % 2).astype(np.int64)).cuda()
+        tt = torch.from_numpy(synth.hash_u8(935, (B, cfg.out_h, cfg.out_w))).cuda()
+        res = []
+        for world in (2, 1):
+            eng = Engine(cfg, dtype="bf16", max_batch=B, micro_batch=8)
+            eng.load_params(synth.make_params(cfg))
+            st = DataParallelStepper(eng, dist if world > 1 else None, world=world)
+            for _ in range(2):
+                st.step(xt, tt, ft, mean_elems=B * cfg.pixels, lr=1e-5)
+            res.append((st.global_loss(), eng.flat_params.clone()))
+            del eng
+        assert res[0][0] == res[1][0]
+        assert torch.equal(res[0][1], res[1][1])
+    finally:
+        dist.destroy_process_group()
+
+
 def test_c4_per_gpu_shard_through_the_data_parallel_step():
     """BASELINE configs[3]: the per-GPU shard (C3 net, bf16, 8192 glyphs) through the multi-rank code path (materialised
     gradients -> RCCL all-reduce -> AdamW kernel) over a world of one: the same parameters as the fused single-GPU step
